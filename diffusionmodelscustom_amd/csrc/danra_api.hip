@@ -1,0 +1,837 @@
+// Host runtime of libdanra_hip.so: parameter table, weight packing, workspace, the UNet forward
+// schedule and the DDPM sampling loop.  C ABI declared in include/danra_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/danra_hip.h"
+#include "danra_kernels.h"
+
+using namespace danra;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(DANRA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define RC_TRY(expr)           \
+    do {                       \
+        int rc__ = (expr);     \
+        if (rc__ != DANRA_OK) return rc__; \
+    } while (0)
+
+const int kFmap[5] = {64, 64, 128, 256, 512};  // modules_DANRA_conditional.py:170
+
+struct ParamEntry {
+    std::string name;
+    size_t numel;
+    const float* src = nullptr;
+};
+
+struct ConvP {
+    float* w = nullptr;     // [Cout][KH][KW][Cin] (stem: [Cout][Cin][KH][KW])
+    float* bias = nullptr;  // folded BatchNorm shift or conv bias (may be null)
+    int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
+};
+struct AttnP {
+    float* w_in = nullptr;   // [3C][C], LayerNorm scale folded in
+    float* b_in = nullptr;   // [3C],    LayerNorm shift folded in
+    float* w_out = nullptr;  // [C][C]
+    float* b_out = nullptr;
+    int C = 0;
+};
+struct BlockP {
+    ConvP c1, c2, sc;
+    bool has_sc = false;
+};
+struct DecP {
+    float* wt = nullptr;  // [4*Cin][Cin]
+    float* bt = nullptr;  // [4*Cin]
+    ConvP conv;
+    AttnP attn;
+    int Cin = 0, Cout = 0;
+    int tb_off = 0;
+};
+
+struct Workspace {
+    int B = 0, H = 0, W = 0;
+    void* base = nullptr;
+    size_t bytes = 0;
+    float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
+    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps;
+    int64_t* t_i64;
+    size_t partial_floats = 0;
+};
+
+}  // namespace
+
+struct danra_handle_s {
+    danra_config_t cfg;
+    int in_channels = 1;
+    int tb_width = 0, enc_width = 0;
+    int tb_off_enc[5];
+    std::vector<ParamEntry> params;
+    std::unordered_map<std::string, int> index;
+    // packed model
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool packed = false;
+    ConvP stem, conv2, final_conv;
+    std::vector<BlockP> blocks[4];
+    AttnP attn[9];
+    DecP dec[4];
+    float *final_wt = nullptr, *final_bt = nullptr;
+    float *tw = nullptr, *tb = nullptr;  // time projections [tb_width][dim], [tb_width]
+    float* label_emb = nullptr;
+    float *enc_inv_freq = nullptr, *dec_div = nullptr;
+    std::vector<float> h_enc_inv_freq, h_dec_div;
+    bool freq_dirty = true;
+    Workspace ws;
+};
+
+namespace {
+
+void add_param(danra_handle_s* h, const std::string& name, size_t numel) {
+    h->index[name] = (int)h->params.size();
+    h->params.push_back({name, numel, nullptr});
+}
+void add_bn(danra_handle_s* h, const std::string& p, int C) {
+    add_param(h, p + ".weight", C);
+    add_param(h, p + ".bias", C);
+    add_param(h, p + ".running_mean", C);
+    add_param(h, p + ".running_var", C);
+}
+void add_attn(danra_handle_s* h, const std::string& p, int C) {
+    add_param(h, p + ".layernorm.weight", C);
+    add_param(h, p + ".layernorm.bias", C);
+    add_param(h, p + ".attention.in_proj_weight", (size_t)3 * C * C);
+    add_param(h, p + ".attention.in_proj_bias", (size_t)3 * C);
+    add_param(h, p + ".attention.out_proj.weight", (size_t)C * C);
+    add_param(h, p + ".attention.out_proj.bias", C);
+}
+
+void build_param_table(danra_handle_s* h) {
+    const int dim = h->cfg.time_embedding;
+    add_param(h, "encoder.conv1.weight", (size_t)64 * h->in_channels * 64);
+    add_bn(h, "encoder.bn1", 64);
+    int inpl = 64;
+    for (int L = 1; L <= 4; ++L) {
+        const int planes = 64 << (L - 1);
+        for (int b = 0; b < h->cfg.block_layers[L - 1]; ++b) {
+            const std::string p = "encoder.layer" + std::to_string(L) + "." + std::to_string(b);
+            add_param(h, p + ".conv1.weight", (size_t)planes * inpl * 9);
+            add_bn(h, p + ".bn1", planes);
+            add_param(h, p + ".conv2.weight", (size_t)planes * planes * 9);
+            add_bn(h, p + ".bn2", planes);
+            if (b == 0 && (L > 1 || inpl != planes)) {
+                add_param(h, p + ".downsample.0.weight", (size_t)planes * inpl);
+                add_bn(h, p + ".downsample.1", planes);
+            }
+            inpl = planes;
+        }
+    }
+    for (int i = 0; i < 5; ++i) {
+        const std::string p = "encoder.time_projection_layers." + std::to_string(i) + ".1";
+        add_param(h, p + ".weight", (size_t)kFmap[i] * dim);
+        add_param(h, p + ".bias", kFmap[i]);
+    }
+    for (int i = 0; i < 5; ++i) add_attn(h, "encoder.attention_layers." + std::to_string(i), kFmap[i]);
+    add_param(h, "encoder.conv2.weight", (size_t)64 * 64 * 64);
+    if (h->cfg.num_classes > 0) add_param(h, "encoder.label_emb.weight", (size_t)h->cfg.num_classes * dim);
+    for (int k = 0; k < 4; ++k) {
+        const int cin = kFmap[4 - k], cout = kFmap[3 - k];
+        const std::string p = "decoder.residual_layers." + std::to_string(k);
+        add_attn(h, p + ".attention", cout);
+        add_param(h, p + ".time_projection_layer.1.weight", (size_t)cout * dim);
+        add_param(h, p + ".time_projection_layer.1.bias", cout);
+        add_param(h, p + ".transpose.weight", (size_t)cin * cin * 4);
+        add_param(h, p + ".transpose.bias", cin);
+        add_param(h, p + ".conv.weight", (size_t)cout * cin * 9);
+        add_param(h, p + ".conv.bias", cout);
+    }
+    add_param(h, "decoder.final_layer.transpose.weight", (size_t)64 * 64 * 4);
+    add_param(h, "decoder.final_layer.transpose.bias", 64);
+    add_param(h, "decoder.final_layer.conv.weight", (size_t)h->cfg.out_channels * 64 * 9);
+    add_param(h, "decoder.final_layer.conv.bias", h->cfg.out_channels);
+}
+
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    float* take(size_t floats) {
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += ((floats * sizeof(float) + 255) / 256) * 256;
+        return p;
+    }
+};
+
+const float* src_of(danra_handle_s* h, const std::string& name) {
+    auto it = h->index.find(name);
+    return it == h->index.end() ? nullptr : h->params[it->second].src;
+}
+
+// Lays out (and on the second pass fills) the packed arena.
+int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
+    const int dim = h->cfg.time_embedding;
+    float* scratch_scale = bp.take(512);
+    auto pack_conv_bn = [&](ConvP& c, const std::string& wname, const std::string& bn, int Cin, int Cout, int k,
+                            int stride, int pad) -> int {
+        c.Cin = Cin; c.Cout = Cout; c.KH = c.KW = k; c.stride = stride; c.pad = pad;
+        c.w = bp.take((size_t)Cout * Cin * k * k);
+        c.bias = bp.take(Cout);
+        if (fill) {
+            // scratch_scale is reused by consecutive launches on one stream: ordered, no hazard
+            HIP_TRY(launch_bn_fold(src_of(h, bn + ".weight"), src_of(h, bn + ".bias"), src_of(h, bn + ".running_mean"),
+                                   src_of(h, bn + ".running_var"), scratch_scale, c.bias, Cout, st));
+            HIP_TRY(launch_pack_conv(src_of(h, wname), scratch_scale, c.w, Cout, Cin, k, k, st));
+        }
+        return DANRA_OK;
+    };
+    auto pack_attn = [&](AttnP& a, const std::string& p, int C) -> int {
+        a.C = C;
+        a.w_in = bp.take((size_t)3 * C * C);
+        a.b_in = bp.take((size_t)3 * C);
+        a.w_out = bp.take((size_t)C * C);
+        a.b_out = bp.take(C);
+        if (fill) {
+            HIP_TRY(launch_pack_inproj(src_of(h, p + ".attention.in_proj_weight"), src_of(h, p + ".attention.in_proj_bias"),
+                                       src_of(h, p + ".layernorm.weight"), src_of(h, p + ".layernorm.bias"), a.w_in,
+                                       a.b_in, C, st));
+            HIP_TRY(hipMemcpyAsync(a.w_out, src_of(h, p + ".attention.out_proj.weight"), (size_t)C * C * 4,
+                                   hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(a.b_out, src_of(h, p + ".attention.out_proj.bias"), (size_t)C * 4,
+                                   hipMemcpyDeviceToDevice, st));
+        }
+        return DANRA_OK;
+    };
+
+    // stem: native OIHW flattening is already [Cout][plane][kh][kw]
+    h->stem.Cin = h->in_channels; h->stem.Cout = 64; h->stem.KH = h->stem.KW = 8; h->stem.stride = 2; h->stem.pad = 3;
+    h->stem.w = bp.take((size_t)64 * h->in_channels * 64);
+    h->stem.bias = nullptr;
+    if (fill)
+        HIP_TRY(hipMemcpyAsync(h->stem.w, src_of(h, "encoder.conv1.weight"), (size_t)64 * h->in_channels * 64 * 4,
+                               hipMemcpyDeviceToDevice, st));
+    RC_TRY(pack_conv_bn(h->conv2, "encoder.conv2.weight", "encoder.bn1", 64, 64, 8, 2, 3));
+    int inpl = 64;
+    for (int L = 1; L <= 4; ++L) {
+        const int planes = 64 << (L - 1);
+        h->blocks[L - 1].resize(h->cfg.block_layers[L - 1]);
+        for (int b = 0; b < h->cfg.block_layers[L - 1]; ++b) {
+            BlockP& blk = h->blocks[L - 1][b];
+            const std::string p = "encoder.layer" + std::to_string(L) + "." + std::to_string(b);
+            const int stride = (b == 0 && L > 1) ? 2 : 1;
+            RC_TRY(pack_conv_bn(blk.c1, p + ".conv1.weight", p + ".bn1", inpl, planes, 3, stride, 1));
+            RC_TRY(pack_conv_bn(blk.c2, p + ".conv2.weight", p + ".bn2", planes, planes, 3, 1, 1));
+            blk.has_sc = (b == 0 && (L > 1 || inpl != planes));
+            if (blk.has_sc)
+                RC_TRY(pack_conv_bn(blk.sc, p + ".downsample.0.weight", p + ".downsample.1", inpl, planes, 1, stride, 0));
+            inpl = planes;
+        }
+    }
+    // time projections: rows = encoder levels 0..4 then decoder blocks 0..3
+    h->tw = bp.take((size_t)h->tb_width * dim);
+    h->tb = bp.take(h->tb_width);
+    if (fill) {
+        for (int i = 0; i < 5; ++i) {
+            const std::string p = "encoder.time_projection_layers." + std::to_string(i) + ".1";
+            HIP_TRY(hipMemcpyAsync(h->tw + (size_t)h->tb_off_enc[i] * dim, src_of(h, p + ".weight"),
+                                   (size_t)kFmap[i] * dim * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->tb + h->tb_off_enc[i], src_of(h, p + ".bias"), (size_t)kFmap[i] * 4,
+                                   hipMemcpyDeviceToDevice, st));
+        }
+    }
+    for (int i = 0; i < 5; ++i) RC_TRY(pack_attn(h->attn[i], "encoder.attention_layers." + std::to_string(i), kFmap[i]));
+    h->label_emb = nullptr;
+    if (h->cfg.num_classes > 0) {
+        h->label_emb = bp.take((size_t)h->cfg.num_classes * dim);
+        if (fill)
+            HIP_TRY(hipMemcpyAsync(h->label_emb, src_of(h, "encoder.label_emb.weight"),
+                                   (size_t)h->cfg.num_classes * dim * 4, hipMemcpyDeviceToDevice, st));
+    }
+    for (int k = 0; k < 4; ++k) {
+        DecP& d = h->dec[k];
+        d.Cin = kFmap[4 - k];
+        d.Cout = kFmap[3 - k];
+        const std::string p = "decoder.residual_layers." + std::to_string(k);
+        d.wt = bp.take((size_t)4 * d.Cin * d.Cin);
+        d.bt = bp.take((size_t)4 * d.Cin);
+        d.conv.Cin = d.Cin; d.conv.Cout = d.Cout; d.conv.KH = d.conv.KW = 3; d.conv.stride = 1; d.conv.pad = 1;
+        d.conv.w = bp.take((size_t)d.Cout * d.Cin * 9);
+        d.conv.bias = bp.take(d.Cout);
+        if (fill) {
+            HIP_TRY(launch_pack_convT(src_of(h, p + ".transpose.weight"), src_of(h, p + ".transpose.bias"), d.wt, d.bt,
+                                      d.Cin, d.Cin, st));
+            HIP_TRY(launch_pack_conv(src_of(h, p + ".conv.weight"), nullptr, d.conv.w, d.Cout, d.Cin, 3, 3, st));
+            HIP_TRY(hipMemcpyAsync(d.conv.bias, src_of(h, p + ".conv.bias"), (size_t)d.Cout * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->tw + (size_t)d.tb_off * dim, src_of(h, p + ".time_projection_layer.1.weight"),
+                                   (size_t)d.Cout * dim * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->tb + d.tb_off, src_of(h, p + ".time_projection_layer.1.bias"), (size_t)d.Cout * 4,
+                                   hipMemcpyDeviceToDevice, st));
+        }
+        RC_TRY(pack_attn(d.attn, p + ".attention", d.Cout));
+        h->attn[5 + k] = d.attn;
+    }
+    h->final_wt = bp.take((size_t)4 * 64 * 64);
+    h->final_bt = bp.take(4 * 64);
+    h->final_conv.Cin = 64; h->final_conv.Cout = h->cfg.out_channels; h->final_conv.KH = h->final_conv.KW = 3;
+    h->final_conv.stride = 1; h->final_conv.pad = 1;
+    h->final_conv.w = bp.take((size_t)h->cfg.out_channels * 64 * 9);
+    h->final_conv.bias = bp.take(h->cfg.out_channels);
+    if (fill) {
+        HIP_TRY(launch_pack_convT(src_of(h, "decoder.final_layer.transpose.weight"),
+                                  src_of(h, "decoder.final_layer.transpose.bias"), h->final_wt, h->final_bt, 64, 64, st));
+        HIP_TRY(launch_pack_conv(src_of(h, "decoder.final_layer.conv.weight"), nullptr, h->final_conv.w,
+                                 h->cfg.out_channels, 64, 3, 3, st));
+        HIP_TRY(hipMemcpyAsync(h->final_conv.bias, src_of(h, "decoder.final_layer.conv.bias"),
+                               (size_t)h->cfg.out_channels * 4, hipMemcpyDeviceToDevice, st));
+    }
+    h->enc_inv_freq = bp.take(dim / 2);
+    h->dec_div = bp.take(dim / 2);
+    return DANRA_OK;
+}
+
+int upload_freq(danra_handle_s* h, hipStream_t st) {
+    if (!h->freq_dirty) return DANRA_OK;
+    const size_t n = h->cfg.time_embedding / 2;
+    HIP_TRY(hipMemcpyAsync(h->enc_inv_freq, h->h_enc_inv_freq.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->dec_div, h->h_dec_div.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors may change afterwards
+    h->freq_dirty = false;
+    return DANRA_OK;
+}
+
+int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
+    Workspace& ws = h->ws;
+    if (ws.base && ws.B == B && ws.H == H && ws.W == W) return DANRA_OK;
+    if (ws.base) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(ws.base));
+        ws.base = nullptr;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        Bump bp(pass ? ws.base : nullptr);
+        const size_t hw2 = (size_t)(H / 2) * (W / 2), hw4 = (size_t)(H / 4) * (W / 4);
+        ws.tbias = bp.take((size_t)B * h->tb_width);
+        ws.t_i64 = (int64_t*)bp.take((size_t)B * 2);
+        ws.f1pre = bp.take(B * hw2 * 64);
+        ws.c2 = bp.take(B * hw4 * 64);
+        for (int i = 0; i < 4; ++i) ws.rt[i] = bp.take(B * hw4 * 64);
+        size_t hw = hw2;
+        for (int i = 0; i < 5; ++i) {
+            ws.fpre[i] = (i == 0) ? ws.f1pre : bp.take(B * hw * kFmap[i]);
+            ws.fmap[i] = bp.take(B * hw * kFmap[i]);
+            hw /= 4;
+        }
+        ws.qkv = bp.take(3 * B * hw2 * 64);
+        ws.obuf = bp.take(B * hw2 * 64);
+        ws.up = bp.take((size_t)B * H * W * 64);
+        ws.cv = bp.take(B * hw2 * 64);
+        ws.pre = bp.take(B * hw2 * 64);
+        ws.outA = bp.take(B * hw2 * 64);
+        ws.outB = bp.take(B * hw2 * 64);
+        ws.mean1 = bp.take((size_t)B * 512);
+        ws.rstd1 = bp.take((size_t)B * 512);
+        ws.mean2 = bp.take((size_t)B * 512);
+        ws.rstd2 = bp.take((size_t)B * 512);
+        ws.eps = bp.take((size_t)B * H * W * h->cfg.out_channels);
+        ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
+        ws.partial = bp.take(ws.partial_floats);
+        if (!pass) {
+            ws.bytes = bp.off;
+            if (hipMalloc(&ws.base, ws.bytes) != hipSuccess) {
+                ws.base = nullptr;
+                return fail(DANRA_ENOMEM, "workspace allocation of %zu bytes failed", ws.bytes);
+            }
+        }
+    }
+    ws.B = B; ws.H = H; ws.W = W;
+    return DANRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// op launchers shared by the forward schedule and the per-op entry points
+
+void choose_split(IGemmArgs& a, const Workspace& ws) {
+    a.ksplit = 1;
+    a.chunks_per_split = a.K / 32;
+    const int chunks = a.K / 32;
+    const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
+    if (tiles >= 192 || chunks < 8 || !ws.partial) return;
+    int want = (int)((384 + tiles - 1) / tiles);
+    int maxs = chunks / 4;
+    if (want > maxs) want = maxs;
+    while (want > 1 && (size_t)want * a.M * a.N > ws.partial_floats) --want;
+    if (want <= 1) return;
+    a.chunks_per_split = (chunks + want - 1) / want;
+    a.ksplit = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.partial = ws.partial;
+}
+
+IGemmArgs blank_args() {
+    IGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ksplit = 1;
+    a.rows_per_img = 1;
+    return a;
+}
+
+int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int B, int Hi, int Wi, const float* res,
+             int relu, const float* tbias, const float* nmean, const float* nrstd, hipStream_t st) {
+    IGemmArgs a = blank_args();
+    const int Ho = (Hi + 2 * c.pad - c.KH) / c.stride + 1, Wo = (Wi + 2 * c.pad - c.KW) / c.stride + 1;
+    a.A = in; a.W = c.w; a.bias = c.bias; a.res = res; a.tbias = tbias; a.out = out;
+    a.nmean = nmean; a.nrstd = nrstd;
+    a.M = B * Ho * Wo; a.N = c.Cout; a.K = c.KH * c.KW * c.Cin;
+    a.a_mode = A_CONV;
+    a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
+    a.ldr = c.Cout; a.relu = relu; a.tb_stride = h->tb_width; a.rows_per_img = Ho * Wo;
+    a.st_mode = ST_ROW; a.ldc = c.Cout;
+    if (c.Cin % 32 || c.Cout % 64) return fail(DANRA_EINVAL, "conv channels %d->%d unsupported", c.Cin, c.Cout);
+    choose_split(a, h->ws);
+    HIP_TRY(launch_igemm(a, st));
+    return DANRA_OK;
+}
+
+int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B, int H, int W, const float* tbias,
+             hipStream_t st) {
+    IGemmArgs a = blank_args();
+    const ConvP& c = h->stem;
+    for (int i = 0; i < 4; ++i) a.planes[i] = planes[i];
+    a.W = c.w; a.tbias = tbias; a.out = out;
+    a.M = B * (H / 2) * (W / 2); a.N = 64; a.K = 64 * c.Cin;
+    a.a_mode = A_CONV1;
+    a.Hi = H; a.Wi = W; a.Cin = c.Cin; a.Ho = H / 2; a.Wo = W / 2; a.KH = 8; a.KW = 8; a.stride = 2; a.pad = 3;
+    a.tb_stride = h->tb_width; a.rows_per_img = (H / 2) * (W / 2);
+    a.st_mode = ST_ROW; a.ldc = 64;
+    HIP_TRY(launch_igemm(a, st));
+    return DANRA_OK;
+}
+
+int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st) {
+    const AttnP& at = h->attn[index];
+    const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
+    Workspace& ws = h->ws;
+    IGemmArgs a = blank_args();
+    a.A = x; a.lda = C; a.ln = 1; a.a_mode = A_GEMM;
+    a.W = at.w_in; a.bias = at.b_in; a.out = ws.qkv;
+    a.M = B * L; a.N = 3 * C; a.K = C;
+    a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
+    a.qkv_plane = (long long)B * L * C;
+    choose_split(a, ws);
+    HIP_TRY(launch_igemm(a, st));
+    const size_t plane = (size_t)B * L * C;
+    HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+    IGemmArgs o = blank_args();
+    o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;
+    o.W = at.w_out; o.bias = at.b_out; o.res = x; o.ldr = C; o.relu = relu; o.out = out;
+    o.M = B * L; o.N = C; o.K = C; o.st_mode = ST_ROW; o.ldc = C;
+    choose_split(o, ws);
+    HIP_TRY(launch_igemm(o, st));
+    return DANRA_OK;
+}
+
+int run_convT(danra_handle_s* h, const float* wt, const float* bt, int C, const float* in, float* out, int B, int Hh,
+              int Ww, hipStream_t st) {
+    IGemmArgs a = blank_args();
+    a.A = in; a.lda = C; a.a_mode = A_GEMM;
+    a.W = wt; a.bias = bt; a.out = out;
+    a.M = B * Hh * Ww; a.N = 4 * C; a.K = C;
+    a.st_mode = ST_CONVT; a.ct_C = C; a.ct_H = Hh; a.ct_W = Ww;
+    choose_split(a, h->ws);
+    HIP_TRY(launch_igemm(a, st));
+    return DANRA_OK;
+}
+
+// One ResNet layer; the output (with the level's time bias added when tbias != null) goes to `out`.
+int run_layer(danra_handle_s* h, int level, const float* x, float* out, int B, int Hi, int Wi, const float* tbias,
+              hipStream_t st) {
+    Workspace& ws = h->ws;
+    const std::vector<BlockP>& blks = h->blocks[level - 1];
+    const float* cur = x;
+    int Hc = Hi, Wc = Wi;
+    for (size_t b = 0; b < blks.size(); ++b) {
+        const BlockP& blk = blks[b];
+        const int Ho = (Hc + 2 - 3) / blk.c1.stride + 1, Wo = (Wc + 2 - 3) / blk.c1.stride + 1;
+        const bool last = (b + 1 == blks.size());
+        float* t1 = ws.rt[0];
+        float* sc = ws.rt[1];
+        float* dst = last ? out : ws.rt[2 + (b & 1)];
+        RC_TRY(run_conv(h, blk.c1, cur, t1, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st));
+        const float* idn = cur;
+        if (blk.has_sc) {
+            RC_TRY(run_conv(h, blk.sc, cur, sc, B, Hc, Wc, nullptr, 0, nullptr, nullptr, nullptr, st));
+            idn = sc;
+        }
+        RC_TRY(run_conv(h, blk.c2, t1, dst, B, Ho, Wo, idn, 1, last ? tbias : nullptr, nullptr, nullptr, st));
+        cur = dst;
+        Hc = Ho; Wc = Wo;
+    }
+    return DANRA_OK;
+}
+
+int run_time_mlp(danra_handle_s* h, const int64_t* t, const int64_t* y, int B, float* enc_out, float* dec_out,
+                 float* tbias, hipStream_t st) {
+    RC_TRY(upload_freq(h, st));
+    TimeMlpArgs a;
+    a.t = t; a.y = (h->cfg.num_classes > 0) ? y : nullptr; a.label_emb = h->label_emb;
+    a.enc_inv_freq = h->enc_inv_freq; a.dec_div = h->dec_div; a.W = h->tw; a.b = h->tb;
+    a.enc_emb_out = enc_out; a.dec_emb_out = dec_out; a.tbias = tbias;
+    a.B = B; a.dim = h->cfg.time_embedding; a.width = h->tb_width; a.enc_width = h->enc_width;
+    HIP_TRY(launch_time_mlp(a, st));
+    return DANRA_OK;
+}
+
+// DecoderBlock k (0..3) given tbias already computed; in [B][Hh][Ww][Cin] -> out [B][2Hh][2Ww][Cout]
+int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* skip, const float* tbias, float* out,
+                      int B, int Hh, int Ww, hipStream_t st) {
+    Workspace& ws = h->ws;
+    const DecP& d = h->dec[k];
+    const int H2 = 2 * Hh, W2 = 2 * Ww;
+    RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
+    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, B, H2 * W2, d.Cin, st));
+    RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
+    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, B, H2 * W2, d.Cout, st));
+    HIP_TRY(launch_in_apply(ws.cv, ws.mean2, ws.rstd2, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width, ws.pre, B,
+                            H2 * W2, d.Cout, st));
+    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st));
+    return DANRA_OK;
+}
+
+int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st) {
+    Workspace& ws = h->ws;
+    RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
+    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, B, 4 * Hh * Ww, 64, st));
+    HIP_TRY(launch_final_conv(ws.up, ws.mean1, ws.rstd1, h->final_conv.w, h->final_conv.bias, eps_nchw, B, 2 * Hh, 2 * Ww,
+                              64, h->cfg.out_channels, st));
+    return DANRA_OK;
+}
+
+int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, const int64_t* y, const float* cond,
+                 const float* lsm, const float* topo, float* eps, int B, int H, int W, hipStream_t st) {
+    Workspace& ws = h->ws;
+    RC_TRY(run_time_mlp(h, t, y, B, nullptr, nullptr, ws.tbias, st));
+    const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    int np = 0;
+    planes[np++] = x;
+    if (h->cfg.has_lsm) planes[np++] = lsm;
+    if (h->cfg.has_topo) planes[np++] = topo;
+    if (h->cfg.has_cond) planes[np++] = cond;
+    RC_TRY(run_stem(h, planes, ws.f1pre, B, H, W, ws.tbias + h->tb_off_enc[0], st));
+    int Hc = H / 2, Wc = W / 2;
+    RC_TRY(run_attention(h, 0, ws.f1pre, ws.fmap[0], B, Hc * Wc, 0, st));
+    RC_TRY(run_conv(h, h->conv2, ws.fmap[0], ws.c2, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st));
+    Hc /= 2; Wc /= 2;
+    const float* cur = ws.c2;
+    for (int L = 1; L <= 4; ++L) {
+        RC_TRY(run_layer(h, L, cur, ws.fpre[L], B, Hc, Wc, ws.tbias + h->tb_off_enc[L], st));
+        if (L > 1) { Hc /= 2; Wc /= 2; }
+        RC_TRY(run_attention(h, L, ws.fpre[L], ws.fmap[L], B, Hc * Wc, 0, st));
+        cur = ws.fmap[L];
+    }
+    const float* din = ws.fmap[4];
+    for (int k = 0; k < 4; ++k) {
+        float* dout = (k & 1) ? ws.outB : ws.outA;
+        RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st));
+        din = dout;
+        Hc *= 2; Wc *= 2;
+    }
+    RC_TRY(run_final_block(h, din, eps, B, Hc, Wc, st));
+    return DANRA_OK;
+}
+
+int check_ready(danra_handle_s* h, int B, int H, int W) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    if (!h->packed) return fail(DANRA_ESTATE, "danra_pack_weights has not been called");
+    if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
+        return fail(DANRA_EINVAL, "B=%d H=%d W=%d: H and W must be positive multiples of 32", B, H, W);
+    return DANRA_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* danra_last_error(void) { return g_err; }
+
+int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
+    if (!cfg || !out) return fail(DANRA_EINVAL, "null argument");
+    if (cfg->time_embedding <= 0 || cfg->time_embedding % 8 || cfg->time_embedding > 512)
+        return fail(DANRA_EINVAL, "time_embedding=%d must be a multiple of 8 and <= 512", cfg->time_embedding);
+    if (cfg->n_heads != 4) return fail(DANRA_EINVAL, "n_heads=%d unsupported (4 only)", cfg->n_heads);
+    if (cfg->out_channels < 1 || cfg->out_channels > 4) return fail(DANRA_EINVAL, "out_channels must be 1..4");
+    for (int i = 0; i < 4; ++i)
+        if (cfg->block_layers[i] < 1 || cfg->block_layers[i] > 8) return fail(DANRA_EINVAL, "block_layers out of range");
+    danra_handle_s* h = new danra_handle_s();
+    h->cfg = *cfg;
+    h->in_channels = 1 + (cfg->has_lsm ? 1 : 0) + (cfg->has_topo ? 1 : 0) + (cfg->has_cond ? 1 : 0);
+    int off = 0;
+    for (int i = 0; i < 5; ++i) { h->tb_off_enc[i] = off; off += kFmap[i]; }
+    h->enc_width = off;
+    for (int k = 0; k < 4; ++k) { h->dec[k].tb_off = off; off += kFmap[3 - k]; }
+    h->tb_width = off;
+    build_param_table(h);
+    const int half = cfg->time_embedding / 2;
+    h->h_enc_inv_freq.resize(half);
+    h->h_dec_div.resize(half);
+    for (int k = 0; k < half; ++k) {
+        const float e = (float)(2 * k) / (float)cfg->time_embedding;  // arange(0, dim, 2).float() / dim
+        h->h_enc_inv_freq[k] = 1.0f / (float)pow(1000.0, (double)e);
+        h->h_dec_div[k] = (float)pow(10000.0, (double)(2 * k) / (double)cfg->time_embedding);
+    }
+    *out = h;
+    return DANRA_OK;
+}
+
+int danra_destroy(danra_handle_t h) {
+    if (!h) return DANRA_OK;
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->ws.base) (void)hipFree(h->ws.base);
+    delete h;
+    return DANRA_OK;
+}
+
+int danra_num_params(danra_handle_t h) { return h ? (int)h->params.size() : 0; }
+const char* danra_param_name(danra_handle_t h, int i) {
+    return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr;
+}
+size_t danra_param_numel(danra_handle_t h, int i) {
+    return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].numel : 0;
+}
+
+int danra_set_param(danra_handle_t h, const char* name, const float* value_dev, size_t numel) {
+    if (!h || !name) return fail(DANRA_EINVAL, "null argument");
+    auto it = h->index.find(name);
+    if (it == h->index.end()) return fail(DANRA_ENAME, "unknown state_dict entry '%s'", name);
+    ParamEntry& p = h->params[it->second];
+    if (p.numel != numel) return fail(DANRA_EINVAL, "'%s': expected %zu elements, got %zu", name, p.numel, numel);
+    if (!value_dev) return fail(DANRA_EINVAL, "'%s': null pointer", name);
+    p.src = value_dev;
+    return DANRA_OK;
+}
+
+int danra_pack_weights(danra_handle_t h, void* stream) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    for (const ParamEntry& p : h->params)
+        if (!p.src) return fail(DANRA_ENAME, "state_dict entry '%s' was never set", p.name.c_str());
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->arena) {
+        Bump probe(nullptr);
+        RC_TRY(layout_and_pack(h, probe, false, st));
+        h->arena_bytes = probe.off;
+        if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
+            h->arena = nullptr;
+            return fail(DANRA_ENOMEM, "weight arena allocation of %zu bytes failed", h->arena_bytes);
+        }
+    }
+    Bump bp(h->arena);
+    RC_TRY(layout_and_pack(h, bp, true, st));
+    h->freq_dirty = true;
+    RC_TRY(upload_freq(h, st));
+    for (ParamEntry& p : h->params) p.src = nullptr;  // borrowed pointers are not kept
+    h->packed = true;
+    return DANRA_OK;
+}
+
+int danra_set_freq_tables(danra_handle_t h, const float* enc_inv_freq, const float* dec_div, int n) {
+    if (!h || !enc_inv_freq || !dec_div) return fail(DANRA_EINVAL, "null argument");
+    if (n != h->cfg.time_embedding / 2) return fail(DANRA_EINVAL, "expected %d entries", h->cfg.time_embedding / 2);
+    memcpy(h->h_enc_inv_freq.data(), enc_inv_freq, (size_t)n * 4);
+    memcpy(h->h_dec_div.data(), dec_div, (size_t)n * 4);
+    h->freq_dirty = true;
+    return DANRA_OK;
+}
+
+int danra_unet_forward(danra_handle_t h, const float* x, const int64_t* t, const int64_t* y, const float* cond,
+                       const float* lsm, const float* topo, float* eps, int B, int H, int W, void* stream) {
+    RC_TRY(check_ready(h, B, H, W));
+    if (!x || !t || !eps) return fail(DANRA_EINVAL, "x, t and eps_out are required");
+    if (h->cfg.has_lsm && !lsm) return fail(DANRA_EINVAL, "lsm_cond is required by this model");
+    if (h->cfg.has_topo && !topo) return fail(DANRA_EINVAL, "topo_cond is required by this model");
+    if (h->cfg.has_cond && !cond) return fail(DANRA_EINVAL, "cond_img is required by this model");
+    RC_TRY(ensure_workspace(h, B, H, W));
+    return forward_impl(h, x, t, y, cond, lsm, topo, eps, B, H, W, (hipStream_t)stream);
+}
+
+int danra_get_fmaps(danra_handle_t h, float* f1, float* f2, float* f3, float* f4, float* f5, void* stream) {
+    if (!h || !h->ws.base) return fail(DANRA_ESTATE, "no forward has run");
+    float* dst[5] = {f1, f2, f3, f4, f5};
+    int hw = (h->ws.H / 2) * (h->ws.W / 2);
+    for (int i = 0; i < 5; ++i) {
+        if (dst[i]) HIP_TRY(launch_nhwc_to_nchw(h->ws.fmap[i], dst[i], h->ws.B, kFmap[i], hw, (hipStream_t)stream));
+        hw /= 4;
+    }
+    return DANRA_OK;
+}
+
+int danra_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3, size_t n,
+                      void* stream) {
+    if (!x || !eps) return fail(DANRA_EINVAL, "null argument");
+    HIP_TRY(launch_ddpm_update(x, eps, noise, c1, c2, c3, n, 0, 0, 0, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_ddpm_update_philox(float* x, const float* eps, float c1, float c2, float c3, size_t n, uint64_t seed,
+                             uint64_t step, void* stream) {
+    if (!x || !eps) return fail(DANRA_EINVAL, "null argument");
+    if (n % 4) return fail(DANRA_EINVAL, "n must be a multiple of 4");
+    HIP_TRY(launch_ddpm_update(x, eps, nullptr, c1, c2, c3, n, 1, seed, step, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
+                 int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
+                 int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,
+                 void* stream) {
+    RC_TRY(check_ready(h, B, H, W));
+    if (!x || !betas || !alphas || !alpha_hat || T < 2) return fail(DANRA_EINVAL, "bad sampling arguments");
+    if (h->cfg.out_channels != 1) return fail(DANRA_EINVAL, "sampling needs out_channels == 1 (eps has x's shape)");
+    if (noise_mode == DANRA_NOISE_HOST && T > 2 && !noise) return fail(DANRA_EINVAL, "host-noise mode needs noise_dev");
+    if (h->cfg.has_lsm && !lsm) return fail(DANRA_EINVAL, "lsm_cond is required by this model");
+    if (h->cfg.has_topo && !topo) return fail(DANRA_EINVAL, "topo_cond is required by this model");
+    if (h->cfg.has_cond && !cond) return fail(DANRA_EINVAL, "cond_img is required by this model");
+    RC_TRY(ensure_workspace(h, B, H, W));
+    hipStream_t st = (hipStream_t)stream;
+    Workspace& ws = h->ws;
+    const size_t n = (size_t)B * H * W;
+    size_t draw = 0;
+    for (int i = T - 1; i >= 1; --i) {
+        HIP_TRY(launch_fill_i64(ws.t_i64, (int64_t)i, B, st));
+        RC_TRY(forward_impl(h, x, ws.t_i64, y, cond, lsm, topo, ws.eps, B, H, W, st));
+        // fp32 scalar arithmetic in the order of diffusion_DANRA_conditional.py:135-157
+        const float alpha = alphas[i], beta = betas[i], ah = alpha_hat[i];
+        const float one_minus_alpha = 1.0f - alpha, one_minus_ah = 1.0f - ah;
+        const float c1 = 1.0f / sqrtf(alpha);
+        const float c2 = one_minus_alpha / sqrtf(one_minus_ah);
+        const float c3 = sqrtf(beta);
+        if (i > 1) {
+            if (noise_mode == DANRA_NOISE_PHILOX)
+                HIP_TRY(launch_ddpm_update(x, ws.eps, nullptr, c1, c2, c3, n, 1, seed, (uint64_t)i, st));
+            else
+                HIP_TRY(launch_ddpm_update(x, ws.eps, noise + draw * n, c1, c2, c3, n, 0, 0, 0, st));
+            ++draw;
+        } else {
+            HIP_TRY(launch_ddpm_update(x, ws.eps, nullptr, c1, c2, c3, n, 0, 0, 0, st));
+        }
+        for (int k = 0; k < n_trace; ++k)
+            if (trace && trace_steps && trace_steps[k] == i)
+                HIP_TRY(hipMemcpyAsync(trace + (size_t)k * n, x, n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return DANRA_OK;
+}
+
+// ---------------------------------------------------------------- per-op entry points
+int danra_tbias_width(danra_handle_t h) { return h ? h->tb_width : 0; }
+
+int danra_time_embed(danra_handle_t h, const int64_t* t, const int64_t* y, int B, float* enc, float* dec, float* tbias,
+                     void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    return run_time_mlp(h, t, y, B, enc, dec, tbias, (hipStream_t)stream);
+}
+
+// The per-op entry points size the workspace for the smallest image whose buffers hold the op.
+static int op_workspace(danra_handle_t h, int B, long tokens64) {
+    // tokens64 = number of 64-channel NHWC pixels per image the op needs at most
+    int side = 32;
+    while ((long)(side / 2) * (side / 2) < tokens64) side *= 2;
+    if (h->ws.base && h->ws.B == B && (long)(h->ws.H / 2) * (h->ws.W / 2) >= tokens64) return DANRA_OK;
+    return ensure_workspace(h, B, side, side);
+}
+
+int danra_attention(danra_handle_t h, int index, const float* x, float* out, int B, int HW, int relu, void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    if (index < 0 || index > 8) return fail(DANRA_EINVAL, "attention index out of range");
+    const int C = h->attn[index].C;
+    RC_TRY(op_workspace(h, B, ((long)HW * C + 63) / 64));
+    return run_attention(h, index, x, out, B, HW, relu, (hipStream_t)stream);
+}
+
+int danra_conv1(danra_handle_t h, const float* x, const float* lsm, const float* topo, const float* cond, float* out,
+                int B, int H, int W, void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    int np = 0;
+    planes[np++] = x;
+    if (h->cfg.has_lsm) planes[np++] = lsm;
+    if (h->cfg.has_topo) planes[np++] = topo;
+    if (h->cfg.has_cond) planes[np++] = cond;
+    for (int i = 0; i < np; ++i)
+        if (!planes[i]) return fail(DANRA_EINVAL, "missing input plane %d", i);
+    return run_stem(h, planes, out, B, H, W, nullptr, (hipStream_t)stream);
+}
+
+int danra_conv2_bn_relu(danra_handle_t h, const float* x, float* out, int B, int H, int W, void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    RC_TRY(op_workspace(h, B, 1));
+    return run_conv(h, h->conv2, x, out, B, H, W, nullptr, 1, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int danra_resnet_layer(danra_handle_t h, int level, const float* x, float* out, int B, int H, int W, void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    if (level < 1 || level > 4) return fail(DANRA_EINVAL, "level must be 1..4");
+    const int cin = level == 1 ? 64 : (64 << (level - 2));
+    RC_TRY(op_workspace(h, B, 4 * (((long)H * W * cin + 63) / 64)));
+    return run_layer(h, level, x, out, B, H, W, nullptr, (hipStream_t)stream);
+}
+
+int danra_decoder_block(danra_handle_t h, int block, const float* fmap, const float* skip, const int64_t* t, float* out,
+                        int B, int H, int W, void* stream) {
+    if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    if (block < 0 || block > 4) return fail(DANRA_EINVAL, "block must be 0..4");
+    hipStream_t st = (hipStream_t)stream;
+    if (block == 4) {
+        RC_TRY(op_workspace(h, B, (long)H * W));
+        if ((long)h->ws.H * h->ws.W < 4L * H * W) RC_TRY(ensure_workspace(h, B, 2 * H, 2 * W));
+        return run_final_block(h, fmap, out, B, H, W, st);
+    }
+    const int cin = h->dec[block].Cin;
+    RC_TRY(op_workspace(h, B, 4 * (((long)H * W * cin + 63) / 64)));
+    if (!t) return fail(DANRA_EINVAL, "t is required");
+    RC_TRY(run_time_mlp(h, t, nullptr, B, nullptr, nullptr, h->ws.tbias, st));
+    return run_decoder_block(h, block, fmap, skip, h->ws.tbias, out, B, H, W, st);
+}
+
+int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* stream) {
+    if (C % 32) return fail(DANRA_EINVAL, "C must be a multiple of 32");
+    float* stats = nullptr;
+    HIP_TRY(hipMalloc((void**)&stats, (size_t)2 * B * C * 4));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_in_stats(x, stats, stats + (size_t)B * C, B, HW, C, st);
+    if (e == hipSuccess) e = launch_in_apply(x, stats, stats + (size_t)B * C, nullptr, nullptr, 0, out, B, HW, C, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(stats);
+    HIP_TRY(e);
+    return DANRA_OK;
+}
+
+int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream) {
+    HIP_TRY(launch_nchw_to_nhwc(src, dst, B, C, HW, (hipStream_t)stream));
+    return DANRA_OK;
+}
+int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void* stream) {
+    HIP_TRY(launch_nhwc_to_nchw(src, dst, B, C, HW, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+}  // extern "C"

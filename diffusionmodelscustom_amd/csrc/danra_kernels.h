@@ -1,0 +1,89 @@
+// Internal launch interface between the host runtime (danra_api.hip) and the gfx950 kernels.
+// Every launcher enqueues on `stream` and returns immediately; shapes are validated by the caller.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace danra {
+
+// ---------------------------------------------------------------- implicit GEMM (convs, linears)
+enum AMode { A_GEMM = 0, A_CONV = 1, A_CONV1 = 2 };
+enum StoreMode { ST_ROW = 0, ST_QKV = 1, ST_CONVT = 2 };
+
+// out[m][n] = epilogue( sum_k A(m,k) * W[n][k] ).
+//   A_GEMM : A(m,k) = A[m*lda + k], optionally LayerNorm-ed per row over the whole K (ln=1).
+//   A_CONV : NHWC input, k = (kh, kw, c), zero padding; optional per-(image,channel) normalisation
+//            (x - nmean) * nrstd of the in-bounds taps (InstanceNorm applied on load).
+//   A_CONV1: up to four [B][Hi][Wi] planes, k = (plane, kh, kw)  (the network's 8x8 stride-2 stem).
+// epilogue: v += bias[n]; v += res[m*ldr+n]; relu; v += tbias[(m / rows_per_img)*tb_stride + n]; store.
+struct IGemmArgs {
+    const float* A;
+    const float* planes[4];
+    const float* W;
+    const float* bias;
+    const float* res;
+    const float* tbias;
+    const float* nmean;
+    const float* nrstd;
+    float* out;
+    float* partial;  // split-K slabs [ksplit][M][N]
+    int M, N, K;
+    int lda;
+    int a_mode;
+    int ln;
+    int Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad;
+    int ldr, relu, tb_stride, rows_per_img;
+    int st_mode, ldc;
+    int qkv_C, qkv_hd, qkv_L, qkv_heads;
+    long long qkv_plane;
+    int ct_C, ct_H, ct_W;
+    int ksplit, chunks_per_split;
+};
+hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention
+// q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
+hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads,
+                            int L, int hd, hipStream_t stream);
+
+// ---------------------------------------------------------------- small kernels
+struct TimeMlpArgs {
+    const int64_t* t;
+    const int64_t* y;          // may be null
+    const float* label_emb;    // [num_classes][dim] or null
+    const float* enc_inv_freq; // [dim/2]
+    const float* dec_div;      // [dim/2]
+    const float* W;            // [width][dim]
+    const float* b;            // [width]
+    float* enc_emb_out;        // [B][dim] or null
+    float* dec_emb_out;        // [B][dim] or null
+    float* tbias;              // [B][width] or null
+    int B, dim, width, enc_width;
+};
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
+
+hipError_t launch_in_stats(const float* x, float* mean, float* rstd, int B, int HW, int C, hipStream_t stream);
+// out = (x - mean)*rstd [+ skip] [+ tbias[b][c]]
+hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip,
+                           const float* tbias, int tb_stride, float* out, int B, int HW, int C, hipStream_t stream);
+// 3x3 pad-1 conv Cin -> Cout (Cout <= 4) with InstanceNorm on load, NHWC in, NCHW out.
+hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
+                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
+                              size_t n, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
+hipError_t launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
+
+// ---------------------------------------------------------------- weight packing
+hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                          float* scale, float* shift, int C, hipStream_t stream);
+hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_ohwi, int O, int I, int KH, int KW,
+                            hipStream_t stream);
+hipError_t launch_pack_convT(const float* w_iokk, const float* bias, float* w_out, float* bias_out, int Ci, int Co,
+                             hipStream_t stream);
+hipError_t launch_pack_inproj(const float* w_in, const float* b_in, const float* ln_g, const float* ln_b,
+                              float* w_out, float* b_out, int C, hipStream_t stream);
+
+}  // namespace danra

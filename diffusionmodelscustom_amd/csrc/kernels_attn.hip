@@ -1,0 +1,222 @@
+// Self-attention cores on gfx950.
+//
+// k_flash_hd16: head_dim 16 (every 64-channel level: L = 256 / 1024 / 4096 tokens).  Flash-style:
+// no L x L matrix ever leaves the registers.  fp32 matrix cores (v_mfma_f32_16x16x4_f32) compute
+// S^T = K Q^T, so that a lane holds 16 scores of ONE query (q = lane & 15) and the row maximum / sum
+// are lane-local plus two cross-lane exchanges; the same accumulator registers are then the B
+// operand of O^T = V^T P^T without passing through LDS.  Online softmax in the exp2 domain.
+//
+// k_attn_small: every other shape of the network (L <= 256, head_dim 32..128); one wave per query
+// row, K/V of the (image, head) pair resident in LDS.  These shapes hold < 1 % of the FLOPs.
+#include "danra_kernels.h"
+
+namespace danra {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int QT = 2;    // 16-query tiles per wave
+static constexpr int KVT = 64;  // keys per LDS tile
+static constexpr int KROW = 20; // padded LDS row (floats) of a 16-float K/V row: conflict-free b32 column reads
+
+__global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, float* __restrict__ O,
+                                                    int L, int heads, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][KVT * KROW];
+    __shared__ __attribute__((aligned(16))) float Vs[2][KVT * KROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
+    const int lq = lane & 15;  // query column / key row / d column, depending on the operand
+    const int g = lane >> 4;   // k-slot of the MFMA
+
+    const float* Qb = Q + (size_t)bh * L * 16;
+    const float* Kb = K + (size_t)bh * L * 16;
+    const float* Vb = V + (size_t)bh * L * 16;
+
+    // Q fragments: B operand of S^T = K Q^T: lane (q, g) holds Q[q][4g + r] for MFMA step r.
+    float4 qf[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+
+    f32x4 ot[QT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        ot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mrun[t] = -INFINITY;
+        lrun[t] = 0.f;
+    }
+
+    // staging: 64 keys x 16 floats = 256 float4 per operand, one per thread
+    const int srow = tid >> 2, sc4 = (tid & 3) * 4;
+    float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
+    float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * 16 + sc4);
+    *reinterpret_cast<float4*>(&Ks[0][srow * KROW + sc4]) = kreg;
+    *reinterpret_cast<float4*>(&Vs[0][srow * KROW + sc4]) = vreg;
+    __syncthreads();
+
+    const int ntiles = L / KVT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) {
+            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)((kt + 1) * KVT + srow) * 16 + sc4);
+            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)((kt + 1) * KVT + srow) * 16 + sc4);
+        }
+        // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 16j + 4g + r)
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][(j * 16 + lq) * KROW + 4 * g]);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
+                s[t][j] = a;
+            }
+        }
+        // ---- online softmax (per query = per lane & 15; the four lanes g = 0..3 share a query)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = s[t][0][0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[t], mx);
+            const float mc = mnew * scale_log2e;
+            const float alpha = exp2f(mrun[t] * scale_log2e - mc);  // exp2(-inf) = 0 on the first tile
+            mrun[t] = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(fmaf(s[t][j][r], scale_log2e, -mc));
+                    s[t][j][r] = pv;
+                    psum += pv;
+                }
+            lrun[t] = lrun[t] * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
+        }
+        // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[16j + 4g + r][d]), B = P (the S^T registers)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float vf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vf[r] = Vs[buf][(j * 16 + 4 * g + r) * KROW + lq];
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
+        }
+        if (kt + 1 < ntiles) {
+            *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
+            *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (q, g) holds O[q][4g + r], r = 0..3
+    const int b = bh / heads, head = bh - b * heads;
+    const int C = heads * 16;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = lrun[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        float4 o = make_float4(ot[t][0] * inv, ot[t][1] * inv, ot[t][2] * inv, ot[t][3] * inv);
+        *reinterpret_cast<float4*>(O + ((size_t)b * L + q0 + t * 16 + lq) * C + head * 16 + 4 * g) = o;
+    }
+}
+
+// Generic small-shape attention: grid (B*heads, query blocks); K (padded rows) and V in LDS.
+__global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, float* __restrict__ O, int L,
+                                                    int hd, int heads, int q_per_block, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int kst = hd + 1;
+    float* Ks = sm;                        // [L][hd+1]
+    float* Vs = Ks + (size_t)L * kst;      // [L][hd]
+    float* Ps = Vs + (size_t)L * hd;       // [4 waves][L]
+    float* Qs = Ps + 4 * L;                // [4 waves][hd]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x;
+    const float* Qb = Q + (size_t)bh * L * hd;
+    const float* Kb = K + (size_t)bh * L * hd;
+    const float* Vb = V + (size_t)bh * L * hd;
+    for (int i = tid; i < L * hd; i += 256) {
+        const int r = i / hd, c = i - r * hd;
+        Ks[r * kst + c] = Kb[i];
+        Vs[i] = Vb[i];
+    }
+    __syncthreads();
+    const int b = bh / heads, head = bh - b * heads;
+    const int C = heads * hd;
+    const int qbeg = blockIdx.y * q_per_block;
+    const int qend = min(L, qbeg + q_per_block);
+    float* Pw = Ps + wave * L;
+    float* Qw = Qs + wave * hd;
+    for (int q = qbeg + wave; q < qend; q += 4) {
+        for (int d = lane; d < hd; d += 64) Qw[d] = Qb[(size_t)q * hd + d] * scale;
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) {
+            float sacc = 0.f;
+            for (int d = 0; d < hd; ++d) sacc = fmaf(Qw[d], Ks[j * kst + d], sacc);
+            Pw[j] = sacc;
+            mx = fmaxf(mx, sacc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float e = expf(Pw[j] - mx);
+            Pw[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < hd; d += 64) {
+            float oacc = 0.f;
+            for (int j = 0; j < L; ++j) oacc = fmaf(Pw[j], Vs[j * hd + d], oacc);
+            O[((size_t)b * L + q) * C + head * hd + d] = oacc * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                            int hd, hipStream_t stream) {
+    if (hd == 16 && L % 128 == 0) {
+        const float scale_log2e = 0.25f * 1.4426950408889634f;
+        dim3 grid(L / 128, B * heads);
+        hipLaunchKernelGGL(k_flash_hd16, grid, dim3(256), 0, stream, q, k, v, out, L, heads, scale_log2e);
+        return hipGetLastError();
+    }
+    const size_t lds = ((size_t)L * (hd + 1) + (size_t)L * hd + 4 * (size_t)L + 4 * (size_t)hd) * sizeof(float);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_small),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int qblocks = 1;
+    while (B * heads * qblocks < 1024 && L / (qblocks * 2) >= 8) qblocks *= 2;
+    const int qpb = (L + qblocks - 1) / qblocks;
+    dim3 grid(B * heads, qblocks);
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL(k_attn_small, grid, dim3(256), lds, stream, q, k, v, out, L, hd, heads, qpb, scale);
+    return hipGetLastError();
+}
+
+}  // namespace danra

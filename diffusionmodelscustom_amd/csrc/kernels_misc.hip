@@ -1,0 +1,415 @@
+// Small kernels of the DANRA path: time embeddings + projection MLPs, InstanceNorm statistics and
+// application, the 64 -> out_channels output convolution, the DDPM update, layout helpers and the
+// one-off weight packing kernels.
+#include "danra_kernels.h"
+
+namespace danra {
+
+// ------------------------------------------------------------------------------------------------
+// Time embeddings and the nine Sequential(SiLU, Linear(dim, C)) projections.
+// grid (B, SPLIT): every block rebuilds the two embeddings of its image (dim <= 512 values, cheap)
+// and computes its share of the projection outputs, one wave per output row.
+__global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
+    __shared__ float s_enc[512];
+    __shared__ float s_dec[512];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int half = a.dim / 2;
+    const long long ti = a.t[b];
+    const float tf = (float)ti;
+    for (int j = tid; j < a.dim; j += 256) {
+        // encoder: [sin(t*f_0..f_half-1) | cos(...)], base 1000, then + label embedding
+        const int k = j < half ? j : j - half;
+        const float arg = tf * a.enc_inv_freq[k];
+        float e = j < half ? sinf(arg) : cosf(arg);
+        if (a.y) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
+        // decoder: interleaved sin/cos of t / 10000^(2k/dim)
+        const int kd = j >> 1;
+        const float argd = tf / a.dec_div[kd];
+        const float d = (j & 1) ? cosf(argd) : sinf(argd);
+        if (blockIdx.y == 0) {
+            if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
+            if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d;
+        }
+        s_enc[j] = e / (1.0f + expf(-e));  // SiLU
+        s_dec[j] = d / (1.0f + expf(-d));
+    }
+    __syncthreads();
+    if (!a.tbias) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (a.width + gridDim.y - 1) / gridDim.y;
+    const int o_beg = blockIdx.y * per;
+    const int o_end = min(a.width, o_beg + per);
+    for (int o = o_beg + wave; o < o_end; o += 4) {
+        const float* w = a.W + (size_t)o * a.dim;
+        const float* s = o < a.enc_width ? s_enc : s_dec;
+        float acc = 0.f;
+        for (int k = lane * 4; k < a.dim; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + k);
+            acc = fmaf(wv.x, s[k], acc);
+            acc = fmaf(wv.y, s[k + 1], acc);
+            acc = fmaf(wv.z, s[k + 2], acc);
+            acc = fmaf(wv.w, s[k + 3], acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) a.tbias[(size_t)b * a.width + o] = acc + a.b[o];
+    }
+}
+
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_time_mlp, dim3(a.B, 8), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm statistics on NHWC: block = (image, 32 channels); 8 channel quads x 32 pixel slots.
+// Two passes (mean, then centred sum of squares) so that the biased variance matches a direct
+// evaluation; the second pass re-reads from L2.
+__global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
+                                                  float* __restrict__ rstd, int HW, int C) {
+    __shared__ float4 red[256];
+    const int b = blockIdx.x;
+    const int c0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int cq = (tid & 7) * 4;
+    const int slot = tid >> 3;
+    const float* base = x + (size_t)b * HW * C + c0 + cq;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = slot; p < HW; p += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= 8; st >>= 1) {
+        if (tid < st) {
+            float4 o = red[tid + st];
+            float4 m = red[tid];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[tid] = m;
+        }
+        __syncthreads();
+    }
+    float4 mu = red[tid & 7];
+    const float inv = 1.0f / (float)HW;
+    mu.x *= inv; mu.y *= inv; mu.z *= inv; mu.w *= inv;
+    __syncthreads();
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = slot; p < HW; p += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
+        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    }
+    red[tid] = q;
+    __syncthreads();
+    for (int st = 128; st >= 8; st >>= 1) {
+        if (tid < st) {
+            float4 o = red[tid + st];
+            float4 m = red[tid];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[tid] = m;
+        }
+        __syncthreads();
+    }
+    if (tid < 8) {
+        const float4 var = red[tid];
+        float4 r;
+        r.x = 1.0f / sqrtf(var.x * inv + 1e-5f);
+        r.y = 1.0f / sqrtf(var.y * inv + 1e-5f);
+        r.z = 1.0f / sqrtf(var.z * inv + 1e-5f);
+        r.w = 1.0f / sqrtf(var.w * inv + 1e-5f);
+        *reinterpret_cast<float4*>(mean + (size_t)b * C + c0 + cq) = mu;
+        *reinterpret_cast<float4*>(rstd + (size_t)b * C + c0 + cq) = r;
+    }
+}
+
+hipError_t launch_in_stats(const float* x, float* mean, float* rstd, int B, int HW, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_in_stats, dim3(B, C / 32), dim3(256), 0, stream, x, mean, rstd, HW, C);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ skip,
+                                                  const float* __restrict__ tbias, int tb_stride,
+                                                  float* __restrict__ out, size_t total4, int HW, int C) {
+    const int c4n = C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % c4n) * 4;
+        const size_t b = i / ((size_t)HW * c4n);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + b * C + cq);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + b * C + cq);
+        v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y; v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+        if (skip) {
+            const float4 s = reinterpret_cast<const float4*>(skip)[i];
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        if (tbias) {
+            const float4 t = *reinterpret_cast<const float4*>(tbias + b * tb_stride + cq);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip, const float* tbias,
+                           int tb_stride, float* out, int B, int HW, int C, hipStream_t stream) {
+    const size_t total4 = (size_t)B * HW * C / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_in_apply, dim3(blocks), dim3(256), 0, stream, x, mean, rstd, skip, tbias, tb_stride, out,
+                       total4, HW, C);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output convolution: 3x3, pad 1, Cin (64) -> Cout (<= 4), operand InstanceNorm-ed on load, NCHW out.
+// The normalisation is folded into per-image weights in LDS: w'[tap][c] = w*rstd, and the constant
+// sum_c w*rstd*mean is subtracted per in-bounds tap, so the inner loop is a plain dot product.
+__global__ __launch_bounds__(256) void k_final_conv(const float* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                    int W, int Cin, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wn = sm;                    // [Cout][9][Cin]  w * rstd
+    float* wc = sm + Cout * 9 * Cin;   // [Cout][9]       sum_c w * rstd * mean
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < Cout * 9 * Cin; i += 256) {
+        const int c = i % Cin;
+        wn[i] = w[i] * rstd[(size_t)b * Cin + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < Cout * 9; i += 256) {
+        float s = 0.f;
+        for (int c = 0; c < Cin; ++c) s += wn[i * Cin + c] * mean[(size_t)b * Cin + c];
+        wc[i] = s;
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + tid;
+    if (pix >= H * W) return;
+    const int oy = pix / W, ox = pix - oy * W;
+    const float* xb = x + (size_t)b * H * W * Cin;
+    for (int co = 0; co < Cout; ++co) {
+        float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const float* px = xb + ((size_t)iy * W + ix) * Cin;
+            const float* wt = wn + (co * 9 + tap) * Cin;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int c = 0; c < Cin; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(px + c);
+                const float4 ww = *reinterpret_cast<const float4*>(wt + c);
+                s0 = fmaf(v.x, ww.x, s0); s1 = fmaf(v.y, ww.y, s1); s2 = fmaf(v.z, ww.z, s2); s3 = fmaf(v.w, ww.w, s3);
+            }
+            acc += ((s0 + s1) + (s2 + s3)) - wc[co * 9 + tap];
+        }
+        out[((size_t)b * Cout + co) * H * W + pix] = acc;
+    }
+}
+
+hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
+                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+    const size_t lds = ((size_t)Cout * 9 * Cin + Cout * 9) * sizeof(float);
+    hipLaunchKernelGGL(k_final_conv, dim3((H * W + 255) / 256, B), dim3(256), lds, stream, x, mean, rstd, w, bias, out,
+                       H, W, Cin, Cout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// DDPM update.  __fmul_rn/__fadd_rn/__fsub_rn keep the compiler from contracting into FMAs, so the
+// result is bit-identical to evaluating the reference's two statements op by op in fp32.
+__device__ __forceinline__ float ddpm_one(float x, float e, float z, float c1, float c2, float c3) {
+    const float t = __fmul_rn(c1, __fsub_rn(x, __fmul_rn(c2, e)));
+    return __fadd_rn(t, __fmul_rn(c3, z));
+}
+
+// Philox4x32-10 (Salmon et al.), counter = (element quad, step offset), key = seed.
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                        uint32_t* r) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+}
+
+__global__ __launch_bounds__(256) void k_ddpm_update(float* __restrict__ x, const float* __restrict__ eps,
+                                                     const float* __restrict__ noise, float c1, float c2, float c3,
+                                                     size_t n4, int philox, uint64_t seed, uint64_t offset) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 xv = reinterpret_cast<float4*>(x)[i];
+        const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (philox) {
+            uint32_t r[4];
+            philox4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                    (uint32_t)(seed >> 32), r);
+            box_muller(r[0], r[1], z.x, z.y);
+            box_muller(r[2], r[3], z.z, z.w);
+        } else if (noise) {
+            z = reinterpret_cast<const float4*>(noise)[i];
+        }
+        xv.x = ddpm_one(xv.x, ev.x, z.x, c1, c2, c3);
+        xv.y = ddpm_one(xv.y, ev.y, z.y, c1, c2, c3);
+        xv.z = ddpm_one(xv.z, ev.z, z.z, c1, c2, c3);
+        xv.w = ddpm_one(xv.w, ev.w, z.w, c1, c2, c3);
+        reinterpret_cast<float4*>(x)[i] = xv;
+    }
+}
+
+__global__ void k_ddpm_update_tail(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
+                                   size_t begin, size_t n) {
+    const size_t i = begin + threadIdx.x;
+    if (i < n) x[i] = ddpm_one(x[i], eps[i], noise ? noise[i] : 0.f, c1, c2, c3);
+}
+
+hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3, size_t n,
+                              int philox, uint64_t seed, uint64_t offset, hipStream_t stream) {
+    const size_t n4 = n / 4;
+    if (n4) {
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_ddpm_update, dim3(blocks), dim3(256), 0, stream, x, eps, noise, c1, c2, c3, n4, philox, seed,
+                           offset);
+    }
+    if (n % 4) {
+        if (philox) return hipErrorInvalidValue;  // image planes are multiples of 1024 elements
+        hipLaunchKernelGGL(k_ddpm_update_tail, dim3(1), dim3(4), 0, stream, x, eps, noise, c1, c2, c3, n4 * 4, n);
+    }
+    return hipGetLastError();
+}
+
+__global__ void k_fill_i64(int64_t* p, int64_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fill_i64, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout helpers (tests and the feature-map export): 32x32 LDS tile transposes.
+__global__ __launch_bounds__(256) void k_transpose_last2(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                         int Cc) {
+    // src [b][R][Cc] -> dst [b][Cc][R]
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* s = src + (size_t)b * R * Cc;
+    float* d = dst + (size_t)b * R * Cc;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < Cc) tile[i][tx] = s[(size_t)(r0 + i) * Cc + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < Cc && r0 + tx < R) d[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(k_transpose_last2, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, dst, C, HW);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(k_transpose_last2, dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(256), 0, stream, src, dst, HW, C);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing (one-off, after load_state_dict).
+__global__ void k_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float* scale,
+                          float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s = (double)gamma[c] / sqrt((double)var[c] + 1e-5);
+    scale[c] = (float)s;
+    shift[c] = (float)((double)beta[c] - (double)mean[c] * s);
+}
+hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float* scale,
+                          float* shift, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_fold, dim3((C + 255) / 256), dim3(256), 0, stream, gamma, beta, mean, var, scale, shift, C);
+    return hipGetLastError();
+}
+
+__global__ void k_pack_conv(const float* w, const float* scale, float* out, int O, int I, int KH, int KW) {
+    const size_t total = (size_t)O * I * KH * KW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        // idx enumerates the OUTPUT layout [o][kh][kw][i]
+        const int i = (int)(idx % I);
+        size_t r = idx / I;
+        const int kw = (int)(r % KW);
+        r /= KW;
+        const int kh = (int)(r % KH);
+        const int o = (int)(r / KH);
+        float v = w[(((size_t)o * I + i) * KH + kh) * KW + kw];
+        if (scale) v = (float)((double)v * (double)scale[o]);
+        out[idx] = v;
+    }
+}
+hipError_t launch_pack_conv(const float* w, const float* scale, float* out, int O, int I, int KH, int KW,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_conv, dim3(1024), dim3(256), 0, stream, w, scale, out, O, I, KH, KW);
+    return hipGetLastError();
+}
+
+__global__ void k_pack_convT(const float* w, const float* bias, float* wout, float* bout, int Ci, int Co) {
+    // w [Ci][Co][2][2] -> wout [(dy*2+dx)*Co + co][ci]; bout = bias tiled over the four sub-pixels
+    const size_t total = (size_t)4 * Co * Ci;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Ci);
+        const int n = (int)(idx / Ci);
+        const int q = n / Co, co = n - q * Co;
+        wout[idx] = w[((size_t)ci * Co + co) * 4 + q];
+        if (ci == 0) bout[n] = bias[co];
+    }
+}
+hipError_t launch_pack_convT(const float* w, const float* bias, float* wout, float* bout, int Ci, int Co,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_convT, dim3(1024), dim3(256), 0, stream, w, bias, wout, bout, Ci, Co);
+    return hipGetLastError();
+}
+
+__global__ void k_pack_inproj(const float* w_in, const float* b_in, const float* g, const float* be, float* wout,
+                              float* bout, int C) {
+    // LayerNorm affine folded into in_proj: W'[n][k] = W[n][k]*g[k]; b'[n] = b[n] + sum_k W[n][k]*beta[k]
+    const int n = blockIdx.x;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < C; k += blockDim.x) {
+        const float wv = w_in[(size_t)n * C + k];
+        wout[(size_t)n * C + k] = wv * g[k];
+        s += (double)wv * (double)be[k];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bout[n] = (float)((double)b_in[n] + red[0]);
+}
+hipError_t launch_pack_inproj(const float* w_in, const float* b_in, const float* g, const float* be, float* wout,
+                              float* bout, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_inproj, dim3(3 * C), dim3(256), 0, stream, w_in, b_in, g, be, wout, bout, C);
+    return hipGetLastError();
+}
+
+}  // namespace danra

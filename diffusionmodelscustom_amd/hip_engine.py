@@ -1,0 +1,239 @@
+"""ctypes binding of libdanra_hip.so (C ABI: include/danra_hip.h).
+
+PyTorch supplies device memory and streams only; every kernel lives in the shared library.
+Loading fails loudly: there is no software fallback for the HIP path.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdanra_hip.so")
+_lib = None
+_lib_lock = threading.Lock()
+
+NOISE_HOST = 0
+NOISE_PHILOX = 1
+
+
+class DanraConfig(ctypes.Structure):
+    _fields_ = [
+        ("has_lsm", ctypes.c_int),
+        ("has_topo", ctypes.c_int),
+        ("has_cond", ctypes.c_int),
+        ("num_classes", ctypes.c_int),
+        ("time_embedding", ctypes.c_int),
+        ("out_channels", ctypes.c_int),
+        ("n_heads", ctypes.c_int),
+        ("block_layers", ctypes.c_int * 4),
+    ]
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "danra_last_error": (ctypes.c_char_p, []),
+    "danra_create": (ctypes.c_int, [ctypes.POINTER(DanraConfig), ctypes.POINTER(_P)]),
+    "danra_destroy": (ctypes.c_int, [_P]),
+    "danra_num_params": (ctypes.c_int, [_P]),
+    "danra_param_name": (ctypes.c_char_p, [_P, ctypes.c_int]),
+    "danra_param_numel": (ctypes.c_size_t, [_P, ctypes.c_int]),
+    "danra_set_param": (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_size_t]),
+    "danra_pack_weights": (ctypes.c_int, [_P, _P]),
+    "danra_set_freq_tables": (ctypes.c_int, [_P, _P, _P, ctypes.c_int]),
+    "danra_unet_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_get_fmaps": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "danra_ddpm_update": (ctypes.c_int, [_P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_size_t, _P]),
+    "danra_ddpm_update_philox": (ctypes.c_int, [_P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_size_t,
+                                                ctypes.c_uint64, ctypes.c_uint64, _P]),
+    "danra_sample": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_int, _P, _P]),
+    "danra_tbias_width": (ctypes.c_int, [_P]),
+    "danra_time_embed": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
+    "danra_attention": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_conv1": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_conv2_bn_relu": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_resnet_layer": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_decoder_block": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_instance_norm": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_nchw_to_nhwc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_nhwc_to_nchw": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libdanra_hip.so once; raise RuntimeError if it was not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RuntimeError(
+                    f"{_LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                    "(or `python -c 'import __graft_entry__ as g; g.build()'`). The HIP path has no fallback.")
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, (restype, argtypes) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.danra_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"{name} must be a CUDA float32 tensor")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    t = t.to(torch.int64)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def reference_freq_tables(dim):
+    """The two frequency tables evaluated with the torch CPU expressions of the reference
+    (modules_DANRA_conditional.py:204-207 and :57), so that they round exactly as it does."""
+    enc = 1.0 / (1000 ** (torch.arange(0, dim, 2).float() / dim))
+    dec = torch.tensor([10000 ** (2 * i / dim) for i in range(dim // 2)], dtype=torch.float64).float()
+    return enc.contiguous(), dec.contiguous()
+
+
+class UNetEngine:
+    """One native handle = one model geometry on one device.  Borrows parameter pointers while
+    packing, owns its packed-weight arena and activation workspace."""
+
+    def __init__(self, *, has_lsm, has_topo, has_cond, num_classes, time_embedding, out_channels, n_heads,
+                 block_layers, device):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        cfg = DanraConfig(int(has_lsm), int(has_topo), int(has_cond), int(num_classes or 0), int(time_embedding),
+                          int(out_channels), int(n_heads), (ctypes.c_int * 4)(*block_layers))
+        self.cfg = cfg
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.danra_create(ctypes.byref(cfg), ctypes.byref(self.handle)), "danra_create")
+        enc, dec = reference_freq_tables(int(time_embedding))
+        _check(self.lib, self.lib.danra_set_freq_tables(self.handle, _ptr(enc), _ptr(dec), enc.numel()),
+               "danra_set_freq_tables")
+        self.out_channels = int(out_channels)
+        self.packed_signature = None
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.danra_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def param_names(self):
+        n = self.lib.danra_num_params(self.handle)
+        return [(self.lib.danra_param_name(self.handle, i).decode(), self.lib.danra_param_numel(self.handle, i))
+                for i in range(n)]
+
+    def pack(self, state_dict):
+        """Register every arithmetic-carrying state_dict entry and repack the arena."""
+        keep = []
+        with torch.cuda.device(self.device):
+            for name, numel in self.param_names():
+                if name not in state_dict:
+                    raise RuntimeError(f"state_dict entry '{name}' is missing")
+                t = state_dict[name].detach()
+                if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.to(device=self.device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                _check(self.lib, self.lib.danra_set_param(self.handle, name.encode(), _ptr(t), t.numel()),
+                       f"danra_set_param({name})")
+            _check(self.lib, self.lib.danra_pack_weights(self.handle, _stream()), "danra_pack_weights")
+            torch.cuda.current_stream().synchronize()  # `keep` may be freed after this
+        del keep
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):
+        x = _f32(x, "x")
+        B, _, H, W = x.shape
+        out = torch.empty((B, self.out_channels, H, W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(self.lib, self.lib.danra_unet_forward(
+                self.handle, _ptr(x), _ptr(_i64(t, "t")), _ptr(_i64(y, "y")), _ptr(_f32(cond_img, "cond_img")),
+                _ptr(_f32(lsm_cond, "lsm_cond")), _ptr(_f32(topo_cond, "topo_cond")), _ptr(out), B, H, W, _stream()),
+                "danra_unet_forward")
+        self._last_shape = (B, H, W, x.device)
+        return out
+
+    def fmaps(self):
+        """The five encoder feature maps of the last forward (Encoder.forward's return value), NCHW."""
+        B, H, W, dev = self._last_shape
+        outs = []
+        side_h, side_w = H // 2, W // 2
+        for ch in (64, 64, 128, 256, 512):
+            outs.append(torch.empty((B, ch, side_h, side_w), device=dev, dtype=torch.float32))
+            side_h //= 2
+            side_w //= 2
+        with torch.cuda.device(dev):
+            _check(self.lib, self.lib.danra_get_fmaps(self.handle, *[_ptr(o) for o in outs], _stream()),
+                   "danra_get_fmaps")
+        return tuple(outs)
+
+    def sample(self, x, y, cond_img, lsm_cond, topo_cond, betas, alphas, alpha_hat, noise=None, seed=0,
+               trace_steps=None):
+        """Whole reverse loop on the device.  x is updated in place and returned.  `noise` (a CUDA
+        tensor [(T-2), B, 1, H, W]) selects host-noise mode, otherwise Philox noise from `seed`."""
+        x = _f32(x, "x")
+        B, _, H, W = x.shape
+        T = int(betas.numel())
+        hb = betas.detach().to("cpu", torch.float32).contiguous()
+        ha = alphas.detach().to("cpu", torch.float32).contiguous()
+        hh = alpha_hat.detach().to("cpu", torch.float32).contiguous()
+        mode = NOISE_PHILOX if noise is None else NOISE_HOST
+        noise = _f32(noise, "noise")
+        trace = None
+        steps_arr = None
+        n_trace = 0
+        if trace_steps:
+            n_trace = len(trace_steps)
+            steps_arr = (ctypes.c_int * n_trace)(*trace_steps)
+            trace = torch.empty((n_trace,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+        yy = _i64(y, "y")
+        cc, ll, tt = _f32(cond_img, "cond_img"), _f32(lsm_cond, "lsm_cond"), _f32(topo_cond, "topo_cond")
+        with torch.cuda.device(x.device):
+            _check(self.lib, self.lib.danra_sample(
+                self.handle, _ptr(x), _ptr(yy), _ptr(cc), _ptr(ll), _ptr(tt), B, H, W, T, _ptr(hb), _ptr(ha), _ptr(hh),
+                mode, _ptr(noise), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                ctypes.cast(steps_arr, ctypes.c_void_p) if steps_arr is not None else None, n_trace, _ptr(trace),
+                _stream()), "danra_sample")
+            # the launches above borrow yy/cc/ll/tt/noise: keep them alive until the stream has run them
+            for keep in (yy, cc, ll, tt, noise):
+                if keep is not None:
+                    keep.record_stream(torch.cuda.current_stream())
+        return (x, trace) if trace_steps else x

@@ -1,0 +1,278 @@
+"""DANRA attention-UNet with the call surface of the reference's ``modules_DANRA_conditional.py``.
+
+Same class names, constructor signatures, parameter/buffer names and registration order as the
+reference (DDPM_DANRA_conditional/modules_DANRA_conditional.py:17-616), so its drivers, training
+pipelines and checkpoints work unchanged (``from modules_DANRA_conditional import *``).
+
+Two execution paths:
+
+* **HIP path** - ``DiffusionNet.forward`` on CUDA fp32 tensors in eval mode with gradients disabled
+  (exactly the situation inside ``DiffusionUtils.sample``) runs entirely in ``libdanra_hip.so``
+  (hand-written gfx950 kernels behind the C ABI of ``include/danra_hip.h``).  If the library is
+  missing this path raises; it never degrades to torch ops.
+* **autograd path** - training mode, gradients enabled, or CPU tensors: a differentiable
+  composition of torch ops with the reference's arithmetic, which is what the reference's training
+  pipeline (training_DANRA_conditional.py:775-1016) needs for backward.
+"""
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from .resnet import BasicBlock, ResNet
+
+__all__ = ["SinusoidalEmbedding", "ImageSelfAttention", "Encoder", "DecoderBlock", "Decoder", "DiffusionNet",
+           "ResNet", "BasicBlock", "torch", "nn", "Optional", "Iterable"]
+
+FMAP_CHANNELS = [64, 64, 128, 256, 512]  # reference modules:170
+
+
+class SinusoidalEmbedding(nn.Module):
+    """Interleaved sin/cos embedding, base ``n`` (reference modules:17-63).
+
+    The reference fills the table with a Python loop over batch x dim/2 scalar tensor ops; this is the
+    same arithmetic vectorised: the integer timestep as fp32 divided by ``n**(2i/dim)`` rounded to fp32."""
+
+    def __init__(self, dim_size, n: int = 10000):
+        assert dim_size % 2 == 0, 'dim_size must be even'
+        super().__init__()
+        self.dim_size = dim_size
+        self.n = n
+
+    def forward(self, x: torch.Tensor):
+        div = torch.tensor([self.n ** (2 * i / self.dim_size) for i in range(self.dim_size // 2)],
+                           dtype=torch.float64).to(device=x.device, dtype=torch.float32)
+        arg = x.reshape(-1).to(torch.float32)[:, None] / div[None, :]
+        return torch.stack((torch.sin(arg), torch.cos(arg)), dim=-1).reshape(arg.shape[0], self.dim_size)
+
+
+class ImageSelfAttention(nn.Module):
+    """LayerNorm -> multi-head self-attention over the H*W tokens -> + un-normalised input
+    (reference modules:67-110)."""
+
+    def __init__(self, input_channels: int, n_heads: int):
+        super().__init__()
+        self.input_channels = input_channels
+        self.n_heads = n_heads
+        self.layernorm = nn.LayerNorm(self.input_channels)
+        self.attention = nn.MultiheadAttention(self.input_channels, self.n_heads, batch_first=True)
+
+    def forward(self, x: torch.Tensor):
+        _, C, H, W = x.shape
+        tokens = x.reshape(-1, C, H * W).permute(0, 2, 1)
+        normed = self.layernorm(tokens)
+        attended, _ = self.attention(normed, normed, normed, need_weights=False)
+        return (attended + tokens).permute(0, 2, 1).reshape(-1, C, H, W)
+
+
+def _time_projections(time_embedding, channels):
+    return nn.ModuleList([nn.Sequential(nn.SiLU(), nn.Linear(time_embedding, ch)) for ch in channels])
+
+
+class Encoder(ResNet):
+    """ResNet-18 encoder with a time bias and self-attention after every stage (reference modules:117-345)."""
+
+    def __init__(self, input_channels: int, time_embedding: int, block=BasicBlock, block_layers: list = [2, 2, 2, 2],
+                 n_heads: int = 4, num_classes: int = None, lsm_tensor=None, topo_tensor=None, cond_on_img=False,
+                 cond_img_dim=None):
+        self.block = block
+        self.block_layers = block_layers
+        self.time_embedding = time_embedding
+        self.input_channels = input_channels
+        self.n_heads = n_heads
+        self.num_classes = num_classes
+        super().__init__(self.block, self.block_layers)
+
+        # one extra input plane per registered conditioning field (reference modules:157-164)
+        if lsm_tensor is not None:
+            self.register_buffer('lsm', lsm_tensor)
+            self.input_channels += 1
+        if topo_tensor is not None:
+            self.register_buffer('elevation', topo_tensor)
+            self.input_channels += 1
+        if cond_on_img:
+            self.input_channels += cond_img_dim[0]
+        self.cond_on_img = bool(cond_on_img)
+
+        self.sinusiodal_embedding = SinusoidalEmbedding(self.time_embedding)
+        self.time_projection_layers = self.make_time_projections(FMAP_CHANNELS)
+        self.attention_layers = self.make_attention_layers(FMAP_CHANNELS)
+        self.conv1 = nn.Conv2d(self.input_channels, 64, kernel_size=(8, 8), stride=(2, 2), padding=(3, 3), bias=False)
+        self.conv2 = nn.Conv2d(64, 64, kernel_size=(8, 8), stride=(2, 2), padding=(3, 3), bias=False)
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes, time_embedding)
+        del self.maxpool, self.fc, self.avgpool
+
+    def pos_encoding(self, t, channels):
+        """[sin | cos] embedding, base 1000 (reference modules:203-211)."""
+        inv_freq = 1.0 / (1000 ** (torch.arange(0, channels, 2).float() / channels))
+        arg = t.repeat(1, channels // 2) * inv_freq.to(t.device)
+        return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
+
+    def make_time_projections(self, fmap_channels: Iterable[int]):
+        return _time_projections(self.time_embedding, fmap_channels)
+
+    def make_attention_layers(self, fmap_channels: Iterable[int]):
+        return nn.ModuleList([ImageSelfAttention(ch, self.n_heads) for ch in fmap_channels])
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
+                cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
+                topo_cond: Optional[torch.Tensor] = None):
+        # channel order x, lsm, topo, cond (reference modules:228-238)
+        planes = [x]
+        if hasattr(self, 'lsm'):
+            planes.append(lsm_cond)
+        if hasattr(self, 'elevation'):
+            planes.append(topo_cond)
+        if cond_img is not None:
+            planes.append(cond_img)
+        x = torch.cat(planes, dim=1) if len(planes) > 1 else x
+
+        emb = self.pos_encoding(t.unsqueeze(-1).type(torch.float), self.time_embedding)
+        if y is not None:
+            emb = emb + self.label_emb(y)
+
+        def stage(level, fmap):
+            fmap = fmap + self.time_projection_layers[level](emb)[:, :, None, None]
+            return self.attention_layers[level](fmap)
+
+        fmap1 = stage(0, self.conv1(x))
+        h = self.relu(self.bn1(self.conv2(fmap1)))
+        fmap2 = stage(1, self.layer1(h))
+        fmap3 = stage(2, self.layer2(fmap2))
+        fmap4 = stage(3, self.layer3(fmap3))
+        fmap5 = stage(4, self.layer4(fmap4))
+        return fmap1, fmap2, fmap3, fmap4, fmap5
+
+
+class DecoderBlock(nn.Module):
+    """convT(k2,s2) - IN - conv3x3 - IN - (+skip) - (+time bias, attention) - activation
+    (reference modules:349-460)."""
+
+    def __init__(self, input_channels: int, output_channels: int, time_embedding: int, upsample_scale: int = 2,
+                 activation: nn.Module = nn.ReLU, compute_attn: bool = True, n_heads: int = 4):
+        super().__init__()
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.upsample_scale = upsample_scale
+        self.time_embedding = time_embedding
+        self.compute_attn = compute_attn
+        self.n_heads = n_heads
+        self.attention = ImageSelfAttention(self.output_channels, self.n_heads) if compute_attn else nn.Identity()
+        self.sinusiodal_embedding = SinusoidalEmbedding(self.time_embedding)
+        self.time_projection_layer = nn.Sequential(nn.SiLU(), nn.Linear(self.time_embedding, self.output_channels))
+        self.transpose = nn.ConvTranspose2d(self.input_channels, self.input_channels,
+                                            kernel_size=self.upsample_scale, stride=self.upsample_scale)
+        self.instance_norm1 = nn.InstanceNorm2d(self.transpose.in_channels)
+        self.conv = nn.Conv2d(self.transpose.out_channels, self.output_channels, kernel_size=3, stride=1, padding=1)
+        self.instance_norm2 = nn.InstanceNorm2d(self.conv.out_channels)
+        self.activation = activation()
+
+    def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
+        out = self.instance_norm2(self.conv(self.instance_norm1(self.transpose(fmap))))
+        if torch.is_tensor(prev_fmap):
+            assert (prev_fmap.shape == out.shape), 'feature maps must be of same shape'
+            out = out + prev_fmap
+        if torch.is_tensor(t):
+            t_emb = self.time_projection_layer(self.sinusiodal_embedding(t))
+            out = self.attention(out + t_emb[:, :, None, None])
+        return self.activation(out)
+
+
+class Decoder(nn.Module):
+    """Four up-sampling blocks with additive skips and a final 64 -> output_channels block
+    (reference modules:465-569)."""
+
+    def __init__(self, last_fmap_channels: int, output_channels: int, time_embedding: int,
+                 first_fmap_channels: int = 64, n_heads: int = 4):
+        super().__init__()
+        self.last_fmap_channels = last_fmap_channels
+        self.output_channels = output_channels
+        self.time_embedding = time_embedding
+        self.first_fmap_channels = first_fmap_channels
+        self.n_heads = n_heads
+        self.residual_layers = self.make_layers()
+        self.final_layer = DecoderBlock(self.residual_layers[-1].input_channels, self.output_channels,
+                                        time_embedding=self.time_embedding, activation=nn.Identity,
+                                        compute_attn=False, n_heads=self.n_heads)
+        self.final_layer.instance_norm2 = nn.Identity()
+
+    def make_layers(self, n: int = 4):
+        layers = []
+        in_ch = self.last_fmap_channels
+        for i in range(n):
+            out_ch = in_ch // 2 if i != (n - 1) else self.first_fmap_channels
+            layers.append(DecoderBlock(in_ch, out_ch, time_embedding=self.time_embedding, compute_attn=True,
+                                       n_heads=self.n_heads))
+            in_ch = out_ch
+        return nn.ModuleList(layers)
+
+    def forward(self, *fmaps, t: Optional[torch.Tensor] = None):
+        deepest_first = list(reversed(fmaps))
+        out = deepest_first[0]
+        for idx, block in enumerate(self.residual_layers):
+            out = block(out, deepest_first[idx + 1], t)
+        return self.final_layer(out)
+
+
+class DiffusionNet(nn.Module):
+    """Encoder + decoder (reference modules:571-616); dispatches to the HIP path when eligible."""
+
+    def __init__(self, encoder: Encoder, decoder: Decoder, lsm_tensor=None, topo_tensor=None, cond_on_img=False,
+                 cond_img_dim=None):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self._hip = None          # (UNetEngine, device)
+        self._hip_signature = None
+
+    # ------------------------------------------------------------------ HIP path plumbing
+    def hip_supported(self):
+        """True when the model has the geometry the native library implements (every reference driver's)."""
+        e, d = self.encoder, self.decoder
+        return (isinstance(e, Encoder) and isinstance(d, Decoder) and e.block is BasicBlock
+                and len(e.block_layers) == 4 and e.n_heads == 4 and d.n_heads == 4
+                and e.time_embedding == d.time_embedding and e.time_embedding % 8 == 0 and e.time_embedding <= 512
+                and d.last_fmap_channels == 512 and d.first_fmap_channels == 64 and 1 <= d.output_channels <= 4
+                and e.conv1.in_channels == 1 + int(hasattr(e, 'lsm')) + int(hasattr(e, 'elevation')) + int(e.cond_on_img))
+
+    def _hip_eligible(self, x):
+        return (not self.training and not torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1
+                and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and self.hip_supported())
+
+    def hip_engine(self, device):
+        """The native engine for `device`, (re)packing weights when any parameter or buffer changed."""
+        from .hip_engine import UNetEngine
+        device = torch.device(device)
+        if self._hip is None or self._hip[1] != device:
+            e = self.encoder
+            engine = UNetEngine(has_lsm=hasattr(e, 'lsm'), has_topo=hasattr(e, 'elevation'), has_cond=e.cond_on_img,
+                                num_classes=e.num_classes or 0, time_embedding=e.time_embedding,
+                                out_channels=self.decoder.output_channels, n_heads=e.n_heads,
+                                block_layers=list(e.block_layers), device=device)
+            self._hip = (engine, device)
+            self._hip_signature = None
+        engine = self._hip[0]
+        sd = self.state_dict(keep_vars=True)
+        signature = tuple((v.data_ptr(), v._version) for v in sd.values())
+        if signature != self._hip_signature:
+            engine.pack(sd)
+            self._hip_signature = signature
+        return engine
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
+                cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
+                topo_cond: Optional[torch.Tensor] = None):
+        if self._hip_eligible(x):
+            if not self.encoder.cond_on_img:
+                cond_img = None if cond_img is None else self._reject_unexpected_cond()
+            return self.hip_engine(x.device).forward(x, t, y if hasattr(self.encoder, 'label_emb') else None,
+                                                     cond_img, lsm_cond, topo_cond)
+        enc_fmaps = self.encoder(x, t=t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)
+        return self.decoder(*enc_fmaps, t=t)
+
+    @staticmethod
+    def _reject_unexpected_cond():
+        raise RuntimeError("cond_img was passed to a model built with cond_on_img=False "
+                           "(conv1 has no input channel for it)")

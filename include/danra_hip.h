@@ -1,0 +1,150 @@
+/*
+ * danra_hip.h - C ABI of libdanra_hip.so: the MI355X (gfx950) implementation of the DANRA
+ * DDPM sampling loop and attention-UNet forward pass.
+ *
+ * The reference (TheaQG/DiffusionModelsCustom) is pure Python: it has no FFI of its own, so each
+ * entry point below names the reference Python interface it replaces (file:line relative to the
+ * reference tree, DDPM_DANRA_conditional/).  All pointers named *_dev are device pointers owned
+ * by the caller (PyTorch tensors in the shipped binding); the library borrows them for the call.
+ * Everything is fp32 except the integer timestep / class tensors (int64, as torch.long).
+ * Every function returns 0 on success or a negative DANRA_E* code and never throws;
+ * danra_last_error() returns the message of the calling thread's last failure.
+ * All kernels are enqueued on the hipStream_t passed as `stream` (void*, 0 = default stream);
+ * no call synchronises the host unless its comment says so.
+ */
+#ifndef DANRA_HIP_H
+#define DANRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANRA_OK 0
+#define DANRA_EINVAL (-1)   /* bad argument / unsupported shape */
+#define DANRA_ESTATE (-2)   /* call order violated (e.g. forward before pack) */
+#define DANRA_EHIP (-3)     /* a HIP runtime call failed */
+#define DANRA_ENOMEM (-4)
+#define DANRA_ENAME (-5)    /* unknown or missing state_dict entry */
+
+typedef struct danra_handle_s* danra_handle_t;
+
+/* Model geometry = the constructor arguments of Encoder/Decoder
+ * (modules_DANRA_conditional.py:124-135, 472-478) after the input-channel arithmetic of :157-164. */
+typedef struct {
+    int has_lsm;         /* encoder.lsm buffer registered  -> lsm_cond plane is concatenated  */
+    int has_topo;        /* encoder.elevation registered   -> topo_cond plane is concatenated */
+    int has_cond;        /* cond_on_img                    -> cond_img plane is concatenated  */
+    int num_classes;     /* 0 = no label embedding */
+    int time_embedding;  /* 256 in every driver; must be even and <= 512 */
+    int out_channels;    /* Decoder output_channels (1) */
+    int n_heads;         /* 4 */
+    int block_layers[4]; /* BasicBlocks per ResNet layer ([2,2,2,2]) */
+} danra_config_t;
+
+const char* danra_last_error(void);
+
+/* Replaces Encoder.__init__/Decoder.__init__/DiffusionNet.__init__ (modules:124-199, 472-509, 576-595):
+ * creates the parameter table, no device memory yet. */
+int danra_create(const danra_config_t* cfg, danra_handle_t* out);
+int danra_destroy(danra_handle_t h);
+
+/* The state_dict contract (keys/shapes of the reference's DiffusionNet.state_dict(); drop-in
+ * checkpoint compatibility, training_DANRA_conditional.py:755-772).  Entries that carry no
+ * arithmetic (num_batches_tracked, encoder.lsm/elevation, final_layer.time_projection_layer) are
+ * not listed and are ignored by danra_set_param. */
+int danra_num_params(danra_handle_t h);
+const char* danra_param_name(danra_handle_t h, int index);
+size_t danra_param_numel(danra_handle_t h, int index);
+
+/* Replaces model.load_state_dict(...) (generation_DANRA_conditional.py:354-359): register the device
+ * pointer of one state_dict entry in its native PyTorch layout.  The pointer is read by the next
+ * danra_pack_weights() only. */
+int danra_set_param(danra_handle_t h, const char* name, const float* value_dev, size_t numel);
+
+/* Re-lay every registered parameter into the library's own arena: conv weights OIHW -> O(HW)I with
+ * eval-mode BatchNorm folded in (modules:271 + BasicBlock), transposed-conv weights as four 1x1
+ * GEMM slabs, LayerNorm affine folded into in_proj.  Must be called after all danra_set_param
+ * calls and again whenever a parameter changes. */
+int danra_pack_weights(danra_handle_t h, void* stream);
+
+/* Optional override of the two sinusoidal frequency tables (n = time_embedding/2 floats each, host
+ * pointers): enc_inv_freq[k] = 1/1000^(2k/dim) (modules:204-207) and dec_div[k] = 10000^(2k/dim)
+ * rounded to fp32 (modules:57).  By default the library computes both in double precision. */
+int danra_set_freq_tables(danra_handle_t h, const float* enc_inv_freq, const float* dec_div, int n);
+
+/* Replaces DiffusionNet.forward(x, t, y, cond_img, lsm_cond, topo_cond) (modules:597-616) in eval
+ * mode.  x/cond/lsm/topo: [B,1,H,W] planes; t_dev: int64[B]; y_dev: int64[B] or NULL;
+ * eps_out_dev: [B,out_channels,H,W].  H and W must be multiples of 32 (five stride-2 stages). */
+int danra_unet_forward(danra_handle_t h, const float* x_dev, const int64_t* t_dev, const int64_t* y_dev,
+                       const float* cond_dev, const float* lsm_dev, const float* topo_dev,
+                       float* eps_out_dev, int B, int H, int W, void* stream);
+
+/* Copies the five encoder feature maps of the last danra_unet_forward (Encoder.forward's return
+ * value, modules:312) to NCHW device buffers; any pointer may be NULL.  For parity tests. */
+int danra_get_fmaps(danra_handle_t h, float* f1, float* f2, float* f3, float* f4, float* f5, void* stream);
+
+/* Replaces diffusion_DANRA_conditional.py:155,157: x = c1*(x - c2*eps); x = x + c3*noise with every
+ * operation rounded to fp32 as torch evaluates it (noise_dev NULL = zeros, the i==1 step). */
+int danra_ddpm_update(float* x_dev, const float* eps_dev, const float* noise_dev, float c1, float c2,
+                      float c3, size_t n, void* stream);
+
+/* The same update with z ~ N(0,1) generated in the kernel: Philox4x32-10 keyed by `seed`, counter =
+ * (element index / 4, step), Box-Muller.  Stands in for torch.randn_like on the device
+ * (diffusion_DANRA_conditional.py:150); n must be a multiple of 4. */
+int danra_ddpm_update_philox(float* x_dev, const float* eps_dev, float c1, float c2, float c3, size_t n,
+                             uint64_t seed, uint64_t step, void* stream);
+
+#define DANRA_NOISE_HOST 0   /* noise_dev holds (T-2) pre-drawn [B,1,H,W] tensors in loop order (i = T-1 ... 2) */
+#define DANRA_NOISE_PHILOX 1 /* Gaussian noise generated inside the update kernel from `seed` */
+
+/* Replaces DiffusionUtils.sample (diffusion_DANRA_conditional.py:105-159): the whole reverse loop
+ * i = T-1 ... 1 on the device, x updated in place.  betas/alphas/alpha_hat are HOST fp32 arrays of
+ * length T (DiffusionUtils.betas/.alphas/.alpha_hat, diffusion:47-51).  trace_dev (may be NULL)
+ * receives x after the update of each timestep listed in trace_steps (host int array, n_trace
+ * entries, [n_trace,B,1,H,W] floats).  Asynchronous on `stream`. */
+int danra_sample(danra_handle_t h, float* x_dev, const int64_t* y_dev, const float* cond_dev,
+                 const float* lsm_dev, const float* topo_dev, int B, int H, int W, int T,
+                 const float* betas, const float* alphas, const float* alpha_hat, int noise_mode,
+                 const float* noise_dev, uint64_t seed, const int* trace_steps, int n_trace,
+                 float* trace_dev, void* stream);
+
+/* ---- per-op entry points (unit parity tests of the kernels; NHWC = [B][H][W][C] fp32) ---- */
+
+/* Sinusoidal embeddings + label embedding + the nine Sequential(SiLU, Linear) projections
+ * (modules:42-63, 203-211, 243-256, 262-305, 449-451).  enc_emb_out/dec_emb_out: [B][time_embedding]
+ * (may be NULL); tbias_out: [B][danra_tbias_width()] laid out encoder level 0..4 then decoder block
+ * 0..3 (may be NULL). */
+int danra_tbias_width(danra_handle_t h);
+int danra_time_embed(danra_handle_t h, const int64_t* t_dev, const int64_t* y_dev, int B,
+                     float* enc_emb_out, float* dec_emb_out, float* tbias_out, void* stream);
+
+/* ImageSelfAttention.forward (modules:91-110) of attention layer `index` (0..4 encoder levels,
+ * 5..8 decoder blocks) on NHWC tokens; relu = the decoder's trailing activation (modules:459). */
+int danra_attention(danra_handle_t h, int index, const float* x_nhwc, float* out_nhwc, int B, int HW,
+                    int relu, void* stream);
+
+/* Encoder.conv1 (modules:178-183, 260) on up to four [B,1,H,W] planes in concatenation order;
+ * out NHWC [B][H/2][W/2][64]. */
+int danra_conv1(danra_handle_t h, const float* x, const float* lsm, const float* topo, const float* cond,
+                float* out_nhwc, int B, int H, int W, void* stream);
+/* Encoder.conv2 + bn1 + relu (modules:186-191, 269-273): NHWC [B][H][W][64] -> [B][H/2][W/2][64]. */
+int danra_conv2_bn_relu(danra_handle_t h, const float* x_nhwc, float* out_nhwc, int B, int H, int W, void* stream);
+/* ResNet layer `level` (1..4) = its BasicBlocks (modules:276,285,294,303): NHWC in/out. */
+int danra_resnet_layer(danra_handle_t h, int level, const float* x_nhwc, float* out_nhwc, int B, int H, int W, void* stream);
+/* DecoderBlock.forward (modules:425-460): block 0..3 = residual_layers, 4 = final_layer (skip/t ignored).
+ * fmap NHWC [B][H][W][Cin] -> out NHWC [B][2H][2W][Cout]; t_dev int64[B]. */
+int danra_decoder_block(danra_handle_t h, int block, const float* fmap_nhwc, const float* skip_nhwc,
+                        const int64_t* t_dev, float* out_nhwc, int B, int H, int W, void* stream);
+/* InstanceNorm2d(affine=False, eps=1e-5) (modules:412,419) on NHWC. */
+int danra_instance_norm(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
+/* NCHW <-> NHWC helpers for the tests. */
+int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream);
+int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANRA_HIP_H */

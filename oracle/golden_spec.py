@@ -1,0 +1,64 @@
+"""Case list and seeded inputs shared by ``oracle/make_golden.py`` (which runs the reference)
+and the tests (which run the CPU restatement and the HIP path on the same inputs).
+
+TEST INFRASTRUCTURE ONLY.  Inputs are regenerated from seeds instead of being stored, so the
+committed fixtures hold only what the reference computed.
+"""
+import torch
+
+from diffusionmodelscustom_amd.synthetic import synthetic_inputs
+
+SEED = 42
+TIME_EMBEDDING = 256
+
+# Model variants exercised by the reference drivers (generation_unconditional.py:133-141,
+# generation_lsm_topo_only.py:137-142, generation_DANRA_conditional.py:280-287).
+VARIANTS = {
+    "uncond": dict(lsm=False, topo=False, cond=False, num_classes=None),
+    "lsm_topo": dict(lsm=True, topo=True, cond=False, num_classes=None),
+    "cond": dict(lsm=True, topo=True, cond=True, num_classes=4),
+}
+
+SCHEDULE_CASES = [(T, s) for T in (200, 800, 1000) for s in ("linear", "cosine")]
+EMBED_TIMESTEPS = (1, 2, 5, 137, 999)
+FORWARD_TIMESTEPS = (1, 500, 999)
+ATTN_LEVELS = ((0, 64, 32), (1, 64, 16), (2, 128, 8), (3, 256, 4), (4, 512, 2))  # (level, C, side)
+CHAIN_CASES = {"T50": dict(T=50, B=2), "T200": dict(T=200, B=2), "T1000": dict(T=1000, B=1)}
+BETA_MIN, BETA_MAX = 1e-4, 0.02
+
+
+def randn(seed, *shape):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def variant_inputs(variant, batch, size, seed=SEED):
+    """Forward-call arguments (x, y, cond_img, lsm_cond, topo_cond) for a model variant."""
+    v = VARIANTS[variant]
+    d = synthetic_inputs(batch, size, size, seed=seed, conditional=True)
+    return dict(
+        x=d["x"],
+        y=d["y"] if v["num_classes"] else None,
+        cond_img=d["cond_img"] if v["cond"] else None,
+        lsm_cond=d["lsm_cond"] if v["lsm"] else None,
+        topo_cond=d["topo_cond"] if v["topo"] else None,
+    )
+
+
+def chain_checkpoints(T):
+    """Timestep indices after whose update x is recorded (diffusion_DANRA_conditional.py:130-157)."""
+    return sorted({T - 1, T - 2, T // 2, 2, 1}, reverse=True)
+
+
+def chain_noise_fn(seed):
+    """Per-step host noise in the reference's draw order: one ``randn`` of x's shape per step with
+    i > 1, from a CPU generator seeded once (diffusion_DANRA_conditional.py:149-152 with
+    torch.manual_seed as in generation_DANRA_conditional.py:41)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def fn(i, x):
+        return torch.randn(x.shape, generator=g)
+
+    return fn

@@ -1,0 +1,24 @@
+"""Helpers shared by the tests: build this package's model for a golden-spec variant."""
+import torch
+
+from diffusionmodelscustom_amd.modules_DANRA_conditional import Decoder, DiffusionNet, Encoder
+from diffusionmodelscustom_amd.synthetic import fill_state_dict_
+from oracle import golden_spec as gs
+
+
+def build_model(variant="cond", size=64, seed=gs.SEED):
+    v = gs.VARIANTS[variant]
+    lsm = torch.zeros(1, size, size) if v["lsm"] else None
+    topo = torch.zeros(1, size, size) if v["topo"] else None
+    enc = Encoder(1, gs.TIME_EMBEDDING, lsm_tensor=lsm, topo_tensor=topo, cond_on_img=v["cond"],
+                  cond_img_dim=(1, size, size) if v["cond"] else None, block_layers=[2, 2, 2, 2],
+                  num_classes=v["num_classes"])
+    dec = Decoder(512, 1, gs.TIME_EMBEDDING, 64)
+    model = DiffusionNet(enc, dec)
+    fill_state_dict_(model, seed)
+    model.eval()
+    return model
+
+
+def state_dict_cpu(model):
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}

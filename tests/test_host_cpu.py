@@ -1,0 +1,141 @@
+"""CPU-side checks of the host layer: checkpoint contract, the autograd path's arithmetic, the
+DiffusionUtils surface, and that the C-ABI library loads and exports every declared symbol.
+No kernel is launched here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN_DIR, ROOT, rel_err
+from model_util import build_model
+from diffusionmodelscustom_amd import DiffusionUtils, hip_engine
+from diffusionmodelscustom_amd.modules_DANRA_conditional import SinusoidalEmbedding
+from oracle import golden_spec as gs
+
+
+@pytest.fixture(scope="module")
+def contract():
+    with open(os.path.join(GOLDEN_DIR, "state_dict.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("variant", list(gs.VARIANTS))
+def test_state_dict_contract(contract, variant):
+    """Keys, registration order, shapes and parameter order equal the reference's (checkpoints drop in)."""
+    m = build_model(variant, 64)
+    got = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    assert got == contract[variant]["state_dict"]
+    assert [k for k, _ in m.named_parameters()] == contract[variant]["parameters"]
+    assert sum(p.numel() for p in m.parameters()) == contract[variant]["n_parameters"]
+
+
+def test_xavier_init_hook_sees_convs():
+    """training_DANRA_conditional.py:739-753 walks the model with isinstance(m, nn.Conv2d | nn.ConvTranspose2d)."""
+    m = build_model("cond", 64)
+    convs = [x for x in m.modules() if isinstance(x, (nn.Conv2d, nn.ConvTranspose2d))]
+    assert len(convs) == 2 + 16 + 3 + 5 + 5  # stem pair, BasicBlock convs, shortcuts, decoder convT + conv
+
+
+def test_autograd_path_matches_golden_forward(golden):
+    g = golden("forward64")
+    m = build_model("cond", 64)
+    inp = gs.variant_inputs("cond", 2, 64)
+    with torch.no_grad():
+        t = torch.full((2,), 500, dtype=torch.long)
+        out = m(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+    assert rel_err(out, g["cond_t500"]) < 5e-6
+
+
+def test_autograd_path_backward():
+    m = build_model("uncond", 32)
+    m.train()
+    x = torch.randn(2, 1, 32, 32)
+    out = m(x, torch.tensor([5, 9]), None, None, None, None)
+    out.pow(2).mean().backward()
+    assert all(p.grad is not None for n, p in m.named_parameters() if "final_layer.time_projection" not in n
+               and "sinusiodal" not in n)
+
+
+def test_sinusoidal_embedding_bit_exact(golden):
+    g = golden("embeddings")
+    t = torch.tensor(g["t"], dtype=torch.long)
+    assert np.array_equal(SinusoidalEmbedding(256)(t).numpy(), g["decoder"])
+    m = build_model("cond", 64)
+    assert np.array_equal(m.encoder.pos_encoding(t.unsqueeze(-1).float(), 256).numpy(), g["encoder"])
+
+
+@pytest.mark.parametrize("T,sched", gs.SCHEDULE_CASES)
+def test_diffusion_utils_schedule(golden, T, sched):
+    g = golden("schedule")
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, "cpu", sched)
+    assert np.array_equal(du.betas.numpy(), g[f"{sched}_{T}_betas"])
+    assert np.array_equal(du.alphas.numpy(), g[f"{sched}_{T}_alphas"])
+    assert np.array_equal(du.alpha_hat.numpy(), g[f"{sched}_{T}_alpha_hat"])
+
+
+def test_diffusion_utils_surface():
+    du = DiffusionUtils(50, 1e-4, 0.02, "cpu", "linear")
+    with pytest.raises(AssertionError, match="x must be a 4D tensor"):
+        du.sample(torch.zeros(4, 4), build_model("uncond", 32))
+    with pytest.raises(AssertionError, match="scheduler must be linear or cosine"):
+        DiffusionUtils(50, 1e-4, 0.02, "cpu", "quadratic")
+    t = du.sampleTimesteps(16)
+    assert t.shape == (16,) and int(t.min()) >= 1 and int(t.max()) < 50
+    xt, noise = du.noiseImage(torch.ones(3, 1, 8, 8), torch.tensor([1, 10, 49]))
+    assert xt.shape == noise.shape == (3, 1, 8, 8)
+
+
+def test_generic_sample_loop_on_cpu_matches_golden_chain(golden):
+    """CPU tensors take the generic step loop (the reference's own control flow) - T=50 chain."""
+    g = golden("chain")
+    m = build_model("cond", 64)
+    du = DiffusionUtils(50, gs.BETA_MIN, gs.BETA_MAX, "cpu", "linear")
+    inp = gs.variant_inputs("cond", 2, 64)
+    fn = gs.chain_noise_fn(gs.SEED + 1)
+    noise = torch.stack([fn(i, inp["x"]) for i in range(49, 1, -1)])
+    out = du.sample_with_host_noise(inp["x"], m, noise, inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"],
+                                    topo_cond=inp["topo_cond"])
+    assert rel_err(out, g["T50_x_after_1"]) < 1e-4
+
+
+def test_skip_shape_assertion():
+    m = build_model("uncond", 32)
+    with pytest.raises(AssertionError, match="feature maps must be of same shape"):
+        m.decoder.residual_layers[0](torch.zeros(1, 512, 1, 1), torch.zeros(1, 256, 3, 3), torch.tensor([1]))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed) and exports each function declared in include/danra_hip.h."""
+    header = open(os.path.join(ROOT, "include", "danra_hip.h")).read()
+    declared = set(re.findall(r"\b(danra_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(hip_engine.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(hip_engine.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_create_rejects_bad_geometry_without_gpu():
+    lib = hip_engine.load_library()
+    cfg = hip_engine.DanraConfig(1, 1, 1, 4, 256, 1, 3, (ctypes.c_int * 4)(2, 2, 2, 2))
+    h = ctypes.c_void_p()
+    assert lib.danra_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"n_heads" in lib.danra_last_error()
+    cfg.n_heads = 4
+    assert lib.danra_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    names = {lib.danra_param_name(h, i).decode() for i in range(lib.danra_num_params(h))}
+    assert "encoder.layer2.0.downsample.0.weight" in names and "encoder.label_emb.weight" in names
+    assert lib.danra_set_param(h, b"encoder.nope", None, 0) == -5
+    assert lib.danra_destroy(h) == 0
+
+
+def test_cuda_inference_without_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(hip_engine, "_lib", None)
+    monkeypatch.setattr(hip_engine, "_LIB_PATH", "/nonexistent/libdanra_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        hip_engine.load_library()

@@ -1,0 +1,119 @@
+"""Pins the CPU restatement (oracle/cpu_ref.py) to the golden vectors that oracle/make_golden.py
+captured from the reference's own code.  CPU only.  Tolerance: 1e-6 * max|reference| (the restatement
+uses the same torch CPU ops; most cases are bit-identical)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from model_util import build_model, state_dict_cpu
+from oracle import cpu_ref
+from oracle import golden_spec as gs
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def sd_cond():
+    return state_dict_cpu(build_model("cond", 64))
+
+
+@pytest.mark.parametrize("T,sched", gs.SCHEDULE_CASES)
+def test_schedule_bit_exact(golden, T, sched):
+    g = golden("schedule")
+    betas, alphas, alpha_hat = cpu_ref.schedule(T, gs.BETA_MIN, gs.BETA_MAX, sched)
+    assert np.array_equal(betas.numpy(), g[f"{sched}_{T}_betas"])
+    assert np.array_equal(alphas.numpy(), g[f"{sched}_{T}_alphas"])
+    assert np.array_equal(alpha_hat.numpy(), g[f"{sched}_{T}_alpha_hat"])
+
+
+def test_embeddings_bit_exact(golden):
+    g = golden("embeddings")
+    t = torch.tensor(g["t"], dtype=torch.long)
+    assert np.array_equal(cpu_ref.encoder_pos_encoding(t).numpy(), g["encoder"])
+    assert np.array_equal(cpu_ref.decoder_sinusoidal_embedding(t).numpy(), g["decoder"])
+    assert np.array_equal(cpu_ref.decoder_sinusoidal_embedding(t[:2], faithful=True).numpy(), g["decoder"][:2])
+
+
+def test_per_op(golden, sd_cond):
+    g = golden("per_op")
+    with torch.no_grad():
+        for lvl, C, side in gs.ATTN_LEVELS:
+            x = gs.randn(100 + lvl, 1, C, side, side)
+            out = cpu_ref.image_self_attention(sd_cond, f"encoder.attention_layers.{lvl}", x)
+            assert rel_err(out, g[f"attn{lvl}"]) < 2e-6, lvl
+        x = gs.randn(110, 1, 4, 64, 64)
+        assert rel_err(torch.nn.functional.conv2d(x, sd_cond["encoder.conv1.weight"], None, 2, 3), g["conv1"]) < TOL
+        for lvl, cin, side in ((1, 64, 16), (2, 64, 16), (3, 128, 8), (4, 256, 4)):
+            x = gs.randn(120 + lvl, 2, cin, side, side)
+            out = cpu_ref.resnet_layer(sd_cond, f"encoder.layer{lvl}", x, 1 if lvl == 1 else 2)
+            assert rel_err(out, g[f"layer{lvl}"]) < TOL, lvl
+        tt = torch.tensor([7], dtype=torch.long)
+        for k, (cin, cout, side) in enumerate(((512, 256, 2), (256, 128, 4), (128, 64, 8), (64, 64, 16))):
+            f = gs.randn(130 + k, 1, cin, side, side)
+            skip = gs.randn(140 + k, 1, cout, 2 * side, 2 * side)
+            out = cpu_ref.decoder_block(sd_cond, f"decoder.residual_layers.{k}", f, skip, tt)
+            assert rel_err(out, g[f"dec{k}"]) < 2e-6, k
+        f = gs.randn(150, 1, 64, 32, 32)
+        assert rel_err(cpu_ref.decoder_block(sd_cond, "decoder.final_layer", f, final=True), g["dec_final"]) < TOL
+
+
+@pytest.mark.parametrize("variant", list(gs.VARIANTS))
+def test_forward64(golden, variant, sd_cond):
+    g = golden("forward64")
+    sd = sd_cond if variant == "cond" else state_dict_cpu(build_model(variant, 64))
+    inp = gs.variant_inputs(variant, 2, 64)
+    with torch.no_grad():
+        for ti in gs.FORWARD_TIMESTEPS:
+            t = torch.full((2,), ti, dtype=torch.long)
+            out = cpu_ref.unet_forward(sd, inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+            assert rel_err(out, g[f"{variant}_t{ti}"]) < 5e-6, (variant, ti)
+
+
+def test_forward_mixed_timesteps_and_fmaps(golden, sd_cond):
+    g = golden("forward64")
+    inp = gs.variant_inputs("cond", 2, 64)
+    with torch.no_grad():
+        t = torch.tensor([3, 731], dtype=torch.long)
+        out = cpu_ref.unet_forward(sd_cond, inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert rel_err(out, g["cond_tmixed"]) < 5e-6
+        inp1 = gs.variant_inputs("cond", 1, 64)
+        fmaps = cpu_ref.encoder_forward(sd_cond, inp1["x"], torch.full((1,), 500, dtype=torch.long), inp1["y"],
+                                        inp1["cond_img"], inp1["lsm_cond"], inp1["topo_cond"])
+        for k, fm in enumerate(fmaps):
+            assert rel_err(fm, g[f"cond_fmap{k + 1}"]) < 5e-6, k
+
+
+def test_forward128(golden):
+    sd = state_dict_cpu(build_model("cond", 128))
+    inp = gs.variant_inputs("cond", 1, 128)
+    with torch.no_grad():
+        out = cpu_ref.unet_forward(sd, inp["x"], torch.full((1,), 500, dtype=torch.long), inp["y"], inp["cond_img"],
+                                   inp["lsm_cond"], inp["topo_cond"])
+    assert rel_err(out, golden("forward128")["cond_t500"]) < 5e-6
+
+
+def test_chain_T50(golden, sd_cond):
+    """Full sampling chain with host noise in the reference's draw order (T=50, B=2)."""
+    g = golden("chain")
+    T = 50
+    inp = gs.variant_inputs("cond", 2, 64)
+    trace = {"want": set(gs.chain_checkpoints(T))}
+    cpu_ref.sample(sd_cond, inp["x"], T, gs.BETA_MIN, gs.BETA_MAX, inp["y"], inp["cond_img"], inp["lsm_cond"],
+                   inp["topo_cond"], noise_fn=gs.chain_noise_fn(gs.SEED + 1), trace=trace)
+    for i in gs.chain_checkpoints(T):
+        assert rel_err(trace[i], g[f"T50_x_after_{i}"]) < 1e-4, i
+
+
+def test_update_matches_reference_statements():
+    betas, alphas, alpha_hat = cpu_ref.schedule(1000, gs.BETA_MIN, gs.BETA_MAX)
+    x, eps, z = gs.randn(1, 2, 1, 8, 8), gs.randn(2, 2, 1, 8, 8), gs.randn(3, 2, 1, 8, 8)
+    for i in (999, 500, 1):
+        c1, c2, c3 = cpu_ref.update_coefficients(betas, alphas, alpha_hat, i)
+        t = torch.full((2,), i, dtype=torch.long)
+        a = alphas[t][:, None, None, None]
+        ah = alpha_hat[t][:, None, None, None]
+        b = betas[t][:, None, None, None]
+        want = (1 / torch.sqrt(a)) * (x - ((1 - a) / torch.sqrt(1 - ah)) * eps)
+        want = want + torch.sqrt(b) * z
+        assert torch.equal(cpu_ref.ddpm_update(x, eps, z, c1, c2, c3), want)
