@@ -1,0 +1,226 @@
+"""Benchmark: sampled images/sec of the 1000-step DDPM sampler (DiffusionUtils.sample through the HIP
+path) on N MI355X GPUs of one node, with the CPU restatement timed beside it.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole sample() call: T-1 = 999 UNet evaluations + 999 DDPM updates for one batch of
+synthetic conditional inputs per GPU (weak scaling: every GPU samples its own batch of the same size;
+no collective inside the loop).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffusionmodelscustom_amd import Decoder, DiffusionNet, DiffusionUtils, Encoder  # noqa: E402
+from diffusionmodelscustom_amd.distributed import broadcast_model_  # noqa: E402
+from diffusionmodelscustom_amd.synthetic import fill_state_dict_, synthetic_inputs  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix/vector peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1..3]
+    "c2": dict(name="DANRA unconditional 64x64, T=1000, batch 32/GPU", size=64, batch=32, cond=False),
+    "c3": dict(name="DANRA conditional (lsm+topo+cond image+season embedding) 64x64, T=1000, batch 64/GPU", size=64,
+               batch=64, cond=True),
+    "c4": dict(name="DANRA conditional 128x128, T=1000, batch 32/GPU", size=128, batch=32, cond=True),
+}
+
+
+def unet_flops_per_image(size, in_ch):
+    """2 x multiply-adds of every convolution, linear and attention product of one UNet evaluation
+    (norms, activations and the softmax itself excluded)."""
+    fl = 0.0
+    s2, s4 = size // 2, size // 4
+
+    def attn(L, C):
+        return 2.0 * L * C * 3 * C + 4.0 * L * L * C + 2.0 * L * C * C
+
+    fl += 2.0 * s2 * s2 * 64 * 64 * in_ch            # conv1 8x8
+    fl += attn(s2 * s2, 64)
+    fl += 2.0 * s4 * s4 * 64 * 64 * 64               # conv2 8x8
+    side, cin = s4, 64
+    for lvl, c in enumerate((64, 128, 256, 512)):
+        if lvl:
+            side //= 2
+        hw = side * side
+        fl += 2.0 * hw * c * cin * 9 + 3 * 2.0 * hw * c * c * 9   # two BasicBlocks
+        if lvl:
+            fl += 2.0 * hw * c * cin                               # 1x1 shortcut
+        fl += attn(hw, c)
+        cin = c
+    for cin, cout in ((512, 256), (256, 128), (128, 64), (64, 64)):
+        side *= 2
+        hw = side * side
+        fl += 2.0 * hw * cin * cin + 2.0 * hw * cout * cin * 9    # convT (one tap per output pixel) + conv3x3
+        fl += attn(hw, cout)
+    side *= 2
+    fl += 2.0 * side * side * 64 * 64 + 2.0 * side * side * 64 * 9
+    fl += 2.0 * 256 * 1536                                        # time projections
+    return fl
+
+
+def build_model(w, seed):
+    size = w["size"]
+    if w["cond"]:
+        enc = Encoder(1, 256, lsm_tensor=torch.zeros(1, size, size), topo_tensor=torch.zeros(1, size, size),
+                      cond_on_img=True, cond_img_dim=(1, size, size), block_layers=[2, 2, 2, 2], num_classes=4)
+    else:
+        enc = Encoder(1, 256, block_layers=[2, 2, 2, 2])
+    model = DiffusionNet(enc, Decoder(512, 1, 256, 64))
+    return fill_state_dict_(model, seed).eval()
+
+
+def cpu_baseline(w, n_steps=4, batch=8):
+    """The CPU restatement (oracle/cpu_ref.py, parity-pinned to the reference) on the host cores: `n_steps`
+    denoise steps (UNet + update) at a reduced batch after one warm-up step, extrapolated to T-1 steps."""
+    from oracle import cpu_ref
+    model = build_model(w, 42)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    inp = synthetic_inputs(batch, w["size"], w["size"], seed=42, conditional=w["cond"])
+    betas, alphas, alpha_hat = cpu_ref.schedule(1000, 1e-4, 0.02)
+    x = inp["x"]
+    times = []
+    with torch.no_grad():
+        for k, i in enumerate(range(999, 999 - (n_steps + 1), -1)):
+            t0 = time.perf_counter()
+            t = torch.full((batch,), i, dtype=torch.long)
+            eps = cpu_ref.unet_forward(sd, x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+            c1, c2, c3 = cpu_ref.update_coefficients(betas, alphas, alpha_hat, i)
+            x = cpu_ref.ddpm_update(x, eps, torch.randn_like(x), c1, c2, c3)
+            if k:
+                times.append(time.perf_counter() - t0)
+    per_step = sum(times) / len(times)
+    return {
+        "value": batch / (per_step * 999),
+        "unit": "images/sec",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{n_steps} denoise steps (UNet forward + update) at batch {batch} after 1 warm-up, "
+                  f"{per_step:.3f} s/step, extrapolated x999; vectorised time embedding (the faster of the two "
+                  f"CPU forms); host cpu_count={os.cpu_count()}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    w = dict(WORKLOADS[args.workload])
+    B = args.batch or w["batch"]
+    T = args.timesteps
+    # rank 0 holds the weights; the other ranks start from a different fill and receive them by broadcast
+    model = build_model(w, 42 if rank == 0 else 1000 + rank).to(dev)
+    sent = broadcast_model_(model, src=0)
+    inp = synthetic_inputs(B, w["size"], w["size"], seed=42 + rank, conditional=w["cond"])
+    inp = {k: (None if v is None else v.to(dev)) for k, v in inp.items()}
+    du = DiffusionUtils(T, 1e-4, 0.02, dev, "linear")
+    du.noise_seed = 42 + rank
+    engine = model.hip_engine(dev)
+
+    def one_step():
+        return du.sample(inp["x"], model, inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"],
+                         topo_cond=inp["topo_cond"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    fence()
+    if not args.no_kernel_timing:
+        engine.profile_begin(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_launches, kern_flops = (0.0, 0, 0.0) if args.no_kernel_timing else engine.profile_end()
+    assert torch.isfinite(out).all()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        images = world * B * args.steps
+        in_ch = 4 if w["cond"] else 1
+        fl_img = unet_flops_per_image(w["size"], in_ch)
+        value = images / elapsed
+        achieved = (kern_flops / (kern_ms * 1e-3) / 1e12) if kern_ms > 0 else None
+        line = {
+            "metric": "sampled images/sec (1000-step DDPM, 64x64) at 1/2/4/8 MI355X vs CPU ref",
+            "value": value,
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded inputs, deterministic random-init weights, in-kernel Philox noise)",
+            "config": {"workload": w["name"], "timesteps": T, "batch_per_gpu": B, "global_batch": world * B,
+                       "image": f"{w['size']}x{w['size']}", "parallelism": f"batch-sharded x{world}, weights broadcast "
+                       f"once ({sent} bytes), no collective in the loop"},
+            "unet_ms": 1e3 * elapsed / args.steps / (T - 1),
+            "flops_per_image_per_unet_eval": fl_img,
+            "whole_path_tflops": value * (T - 1) * fl_img / 1e12 / world,
+            "whole_path_frac_of_fp32_peak": value * (T - 1) * fl_img / 1e12 / world / FP32_MATRIX_PEAK_TFLOPS,
+            "roofline": {
+                "kernel": "k_flash_hd16 (head_dim-16 flash attention: every launch of the timed region, HIP events)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
+                "traffic": None,
+                "launches": kern_launches,
+                "avg_launch_us": (1e3 * kern_ms / kern_launches) if kern_launches else None,
+                "algorithmic_flops_per_launch": (kern_flops / kern_launches) if kern_launches else None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

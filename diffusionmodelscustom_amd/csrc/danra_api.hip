@@ -106,6 +106,11 @@ struct danra_handle_s {
     std::vector<float> h_enc_inv_freq, h_dec_div;
     bool freq_dirty = true;
     Workspace ws;
+    // optional HIP-event timing of one kernel family (danra_profile_begin/_end)
+    int prof_kind = 0;  // 0 = off
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
+    double prof_flops = 0.0;
 };
 
 namespace {
@@ -428,6 +433,16 @@ int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B,
     return DANRA_OK;
 }
 
+int prof_mark(danra_handle_s* h, hipStream_t st) {
+    if (h->prof_used == h->prof_events.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->prof_events.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(h->prof_events[h->prof_used++], st));
+    return DANRA_OK;
+}
+
 int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st) {
     const AttnP& at = h->attn[index];
     const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
@@ -441,7 +456,13 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     choose_split(a, ws);
     HIP_TRY(launch_igemm(a, st));
     const size_t plane = (size_t)B * L * C;
+    const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && hd == 16 && L % 128 == 0);
+    if (timed) RC_TRY(prof_mark(h, st));
     HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+    if (timed) {
+        RC_TRY(prof_mark(h, st));
+        h->prof_flops += 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
+    }
     IGemmArgs o = blank_args();
     o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;
     o.W = at.w_out; o.bias = at.b_out; o.res = x; o.ldr = C; o.relu = relu; o.out = out;
@@ -608,6 +629,7 @@ int danra_destroy(danra_handle_t h) {
     if (!h) return DANRA_OK;
     if (h->arena) (void)hipFree(h->arena);
     if (h->ws.base) (void)hipFree(h->ws.base);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     delete h;
     return DANRA_OK;
 }
@@ -738,6 +760,33 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
             if (trace && trace_steps && trace_steps[k] == i)
                 HIP_TRY(hipMemcpyAsync(trace + (size_t)k * n, x, n * 4, hipMemcpyDeviceToDevice, st));
     }
+    return DANRA_OK;
+}
+
+int danra_profile_begin(danra_handle_t h, int kind) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    if (kind != DANRA_PROF_FLASH_ATTENTION) return fail(DANRA_EINVAL, "unknown kernel family %d", kind);
+    h->prof_kind = kind;
+    h->prof_used = 0;
+    h->prof_flops = 0.0;
+    return DANRA_OK;
+}
+
+int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, double* total_flops) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    double ms = 0.0;
+    const size_t pairs = h->prof_used / 2;
+    if (pairs) HIP_TRY(hipEventSynchronize(h->prof_events[2 * pairs - 1]));
+    for (size_t i = 0; i < pairs; ++i) {
+        float one = 0.f;
+        HIP_TRY(hipEventElapsedTime(&one, h->prof_events[2 * i], h->prof_events[2 * i + 1]));
+        ms += one;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (long long)pairs;
+    if (total_flops) *total_flops = h->prof_flops;
+    h->prof_kind = 0;
+    h->prof_used = 0;
     return DANRA_OK;
 }
 

@@ -220,11 +220,16 @@ hipError_t launch_final_conv(const float* x, const float* mean, const float* rst
 }
 
 // ------------------------------------------------------------------------------------------------
-// DDPM update.  __fmul_rn/__fadd_rn/__fsub_rn keep the compiler from contracting into FMAs, so the
-// result is bit-identical to evaluating the reference's two statements op by op in fp32.
+// DDPM update.  FMA contraction is switched off inside this function (hipcc contracts by default, and
+// HIP's __fmul_rn is a plain multiply), so the result is bit-identical to evaluating the reference's
+// two statements op by op in fp32.
 __device__ __forceinline__ float ddpm_one(float x, float e, float z, float c1, float c2, float c3) {
-    const float t = __fmul_rn(c1, __fsub_rn(x, __fmul_rn(c2, e)));
-    return __fadd_rn(t, __fmul_rn(c3, z));
+#pragma clang fp contract(off)
+    const float t1 = c2 * e;
+    const float t2 = x - t1;
+    const float t3 = c1 * t2;
+    const float t4 = c3 * z;
+    return t3 + t4;
 }
 
 // Philox4x32-10 (Salmon et al.), counter = (element quad, step offset), key = seed.

@@ -49,6 +49,9 @@ _SIGNATURES = {
                                                 ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_sample": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_int, _P, _P]),
+    "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
+    "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
+                                         ctypes.POINTER(ctypes.c_double)]),
     "danra_tbias_width": (ctypes.c_int, [_P]),
     "danra_time_embed": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
     "danra_attention": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
@@ -177,6 +180,17 @@ class UNetEngine:
             _check(self.lib, self.lib.danra_pack_weights(self.handle, _stream()), "danra_pack_weights")
             torch.cuda.current_stream().synchronize()  # `keep` may be freed after this
         del keep
+
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self, kind=1):
+        _check(self.lib, self.lib.danra_profile_begin(self.handle, kind), "danra_profile_begin")
+
+    def profile_end(self):
+        """(total kernel milliseconds, launches, algorithmic FLOPs) of the launches since profile_begin."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        _check(self.lib, self.lib.danra_profile_end(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+               "danra_profile_end")
+        return ms.value, n.value, fl.value
 
     # ------------------------------------------------------------------ hot path
     def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):

@@ -111,6 +111,14 @@ int danra_sample(danra_handle_t h, float* x_dev, const int64_t* y_dev, const flo
                  const float* noise_dev, uint64_t seed, const int* trace_steps, int n_trace,
                  float* trace_dev, void* stream);
 
+/* Measurement hook (no counterpart in the reference, which holds no timing code): between _begin and
+ * _end every launch of the named kernel family is bracketed by HIP events on the stream it is launched
+ * on.  _end waits for the last event (host sync) and returns the summed kernel time, the number of
+ * launches and their algorithmic FLOPs (2 per multiply-add of QK^T and PV). */
+#define DANRA_PROF_FLASH_ATTENTION 1 /* the head_dim-16 flash attention kernel */
+int danra_profile_begin(danra_handle_t h, int kind);
+int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, double* total_flops);
+
 /* ---- per-op entry points (unit parity tests of the kernels; NHWC = [B][H][W][C] fp32) ---- */
 
 /* Sinusoidal embeddings + label embedding + the nine Sequential(SiLU, Linear) projections
