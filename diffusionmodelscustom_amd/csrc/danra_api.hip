@@ -77,7 +77,8 @@ struct Workspace {
     void* base = nullptr;
     size_t bytes = 0;
     float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
-    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps;
+    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part;
+    size_t stats_part_floats = 0;
     int64_t* t_i64;
     size_t partial_floats = 0;
 };
@@ -360,6 +361,8 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         ws.mean2 = bp.take((size_t)B * 512);
         ws.rstd2 = bp.take((size_t)B * 512);
         ws.eps = bp.take((size_t)B * H * W * h->cfg.out_channels);
+        ws.stats_part_floats = (size_t)1 << 19;
+        ws.stats_part = bp.take(ws.stats_part_floats);
         ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
         ws.partial = bp.take(ws.partial_floats);
         if (!pass) {
@@ -378,18 +381,22 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
 // op launchers shared by the forward schedule and the per-op entry points
 
 void choose_split(IGemmArgs& a, const Workspace& ws) {
+    // Split K across workgroups only when there are too few output tiles to give every CU one
+    // (the kernel itself already spreads a chunk's k-blocks over up to 16 waves per workgroup).
     a.ksplit = 1;
     a.chunks_per_split = a.K / 32;
     const int chunks = a.K / 32;
     const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
-    if (tiles >= 192 || chunks < 8 || !ws.partial) return;
-    int want = (int)((384 + tiles - 1) / tiles);
-    int maxs = chunks / 4;
+    if (tiles >= 256 || chunks < 16 || !ws.partial) return;
+    int want = (int)((256 + tiles - 1) / tiles);
+    const int maxs = chunks / 8;
     if (want > maxs) want = maxs;
     while (want > 1 && (size_t)want * a.M * a.N > ws.partial_floats) --want;
     if (want <= 1) return;
-    a.chunks_per_split = (chunks + want - 1) / want;
-    a.ksplit = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    int cps = (chunks + want - 1) / want;
+    cps += cps & 1;  // even, so that 64-deep staging chunks line up
+    a.chunks_per_split = cps;
+    a.ksplit = (chunks + cps - 1) / cps;
     a.partial = ws.partial;
 }
 
@@ -530,9 +537,9 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
     RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
-    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, B, H2 * W2, d.Cin, st));
+    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
     RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
-    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, B, H2 * W2, d.Cout, st));
+    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st));
     HIP_TRY(launch_in_apply(ws.cv, ws.mean2, ws.rstd2, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width, ws.pre, B,
                             H2 * W2, d.Cout, st));
     RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st));
@@ -542,7 +549,7 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
 int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st) {
     Workspace& ws = h->ws;
     RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
-    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, B, 4 * Hh * Ww, 64, st));
+    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
     HIP_TRY(launch_final_conv(ws.up, ws.mean1, ws.rstd1, h->final_conv.w, h->final_conv.bias, eps_nchw, B, 2 * Hh, 2 * Ww,
                               64, h->cfg.out_channels, st));
     return DANRA_OK;
@@ -866,7 +873,7 @@ int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* 
     float* stats = nullptr;
     HIP_TRY(hipMalloc((void**)&stats, (size_t)2 * B * C * 4));
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_in_stats(x, stats, stats + (size_t)B * C, B, HW, C, st);
+    hipError_t e = launch_in_stats(x, stats, stats + (size_t)B * C, nullptr, 0, B, HW, C, st);
     if (e == hipSuccess) e = launch_in_apply(x, stats, stats + (size_t)B * C, nullptr, nullptr, 0, out, B, HW, C, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(stats);

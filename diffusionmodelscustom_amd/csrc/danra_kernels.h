@@ -38,7 +38,9 @@ struct IGemmArgs {
     int qkv_C, qkv_hd, qkv_L, qkv_heads;
     long long qkv_plane;
     int ct_C, ct_H, ct_W;
-    int ksplit, chunks_per_split;
+    int ksplit, chunks_per_split;  // chunks are counted 32-deep
+    int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
+    int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
 
@@ -63,7 +65,9 @@ struct TimeMlpArgs {
 };
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
 
-hipError_t launch_in_stats(const float* x, float* mean, float* rstd, int B, int HW, int C, hipStream_t stream);
+// `part`: scratch of part_floats floats for sliced statistics (may be null: one block per image and 32 channels)
+hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
+                           int C, hipStream_t stream);
 // out = (x - mean)*rstd [+ skip] [+ tbias[b][c]]
 hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip,
                            const float* tbias, int tb_stride, float* out, int B, int HW, int C, hipStream_t stream);

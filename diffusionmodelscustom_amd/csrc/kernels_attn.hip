@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int ntiles = L / KVT;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntiles) {
-            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)((kt + 1) * KVT + srow) * 16 + sc4);
-            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)((kt + 1) * KVT + srow) * 16 + sc4);
+        {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
+            const int nxt = min(kt + 1, ntiles - 1);
+            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
+            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * KVT + srow) * 16 + sc4);
         }
         // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 16j + 4g + r)
         f32x4 s[QT][4];
@@ -116,10 +117,8 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 for (int r = 0; r < 4; ++r)
                     ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
         }
-        if (kt + 1 < ntiles) {
-            *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
-            *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
-        }
+        *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
+        *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
         __syncthreads();
     }
 

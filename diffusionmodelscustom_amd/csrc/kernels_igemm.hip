@@ -4,11 +4,16 @@
 // GEMM slabs + pixel-shuffle store), and the attention in/out projections (with the LayerNorm or
 // InstanceNorm of the operand applied while it is staged into LDS).
 //
-// Tile: BM x 64 outputs per 256-thread workgroup, K walked in chunks of 32 through two LDS buffers;
-// global loads of chunk c+1 are in flight while chunk c is multiplied.  LDS rows are padded to 36
-// floats: 16-byte aligned for ds_write_b128 and conflict-free for the ds_read_b128 fragment reads
-// (lane (i, h) reads k = 8u+4h..8u+4h+3 of row i, so MFMA step r consumes k in {8u+r, 8u+4+r} from
-// both operands).
+// Tile: BM x 64 outputs per workgroup, K walked in chunks of BK through two LDS buffers; the global
+// loads of chunk c+1 are in flight while chunk c is multiplied.  A workgroup has 4*KW waves: four
+// own the 32x32 (BM=64) or 32x64 (BM=128) output sub-tiles, and each group of four takes every KW-th
+// 8-deep k-block of a chunk, so small problems (few output tiles) still put 2-4 waves on every SIMD
+// without an extra kernel; the KW partial accumulators are summed through LDS in a fixed order.
+// Every global load is unconditional (out-of-range rows / padding taps read a clamped address and
+// are zeroed afterwards): a load under a condition makes the compiler wait for it on the spot,
+// which serialises the prefetch.  LDS rows are padded by 4 floats: 16-byte aligned for
+// ds_write_b128 and conflict-free for the ds_read_b128 fragment reads (lane (i, h) reads
+// k = 8u+4h..8u+4h+3 of row i, so MFMA step r consumes k in {8u+r, 8u+4+r} from both operands).
 #include "danra_kernels.h"
 
 namespace danra {
@@ -16,199 +21,160 @@ namespace danra {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int BN = 64;
-static constexpr int BK = 32;
-static constexpr int LDK = 36;
 
-__device__ __forceinline__ void epilogue_store(const IGemmArgs& p, int m, int n, float v) {
-    if (p.bias) v += p.bias[n];
-    if (p.res) v += p.res[(size_t)m * p.ldr + n];
-    if (p.relu) v = fmaxf(v, 0.f);
-    if (p.tbias) v += p.tbias[(size_t)(m / p.rows_per_img) * p.tb_stride + n];
-    if (p.st_mode == ST_ROW) {
-        p.out[(size_t)m * p.ldc + n] = v;
-    } else if (p.st_mode == ST_QKV) {
+// Output address = row part (depends on m) + column part (depends on n), for every store mode.
+__device__ __forceinline__ unsigned long long row_offset(const IGemmArgs& p, int m, int& img) {
+    img = m / p.rows_per_img;
+    if (p.st_mode == ST_ROW) return (unsigned long long)m * p.ldc;
+    if (p.st_mode == ST_QKV) {
+        const int b = m / p.qkv_L;
+        const int l = m - b * p.qkv_L;
+        return ((unsigned long long)b * p.qkv_L * p.qkv_C) + (unsigned long long)l * p.qkv_hd;
+    }
+    const int hw = p.ct_H * p.ct_W;  // ST_CONVT: m = (b, y, x) of the input grid
+    const int b = m / hw;
+    const int r = m - b * hw;
+    const int y = r / p.ct_W;
+    const int x = r - y * p.ct_W;
+    return (((unsigned long long)b * 2 * p.ct_H + 2 * y) * 2 * p.ct_W + 2 * x) * p.ct_C;
+}
+
+__device__ __forceinline__ unsigned long long col_offset(const IGemmArgs& p, int n) {
+    if (p.st_mode == ST_ROW) return n;
+    if (p.st_mode == ST_QKV) {
         const int which = n / p.qkv_C;
         const int cc = n - which * p.qkv_C;
         const int head = cc / p.qkv_hd;
         const int d = cc - head * p.qkv_hd;
-        const int b = m / p.qkv_L;
-        const int l = m - b * p.qkv_L;
-        p.out[(size_t)which * p.qkv_plane + ((size_t)(b * p.qkv_heads + head) * p.qkv_L + l) * p.qkv_hd + d] = v;
-    } else {  // ST_CONVT: n = (dy, dx, co), m = (b, y, x) of the input grid
-        const int q = n / p.ct_C;
-        const int co = n - q * p.ct_C;
-        const int hw = p.ct_H * p.ct_W;
-        const int b = m / hw;
-        const int r = m - b * hw;
-        const int y = r / p.ct_W;
-        const int x = r - y * p.ct_W;
-        const size_t oy = 2 * y + (q >> 1), ox = 2 * x + (q & 1);
-        p.out[(((size_t)b * 2 * p.ct_H + oy) * 2 * p.ct_W + ox) * p.ct_C + co] = v;
+        return (unsigned long long)which * p.qkv_plane + (unsigned long long)head * p.qkv_L * p.qkv_hd + d;
     }
+    const int q = n / p.ct_C;  // n = (dy, dx, co)
+    const int co = n - q * p.ct_C;
+    return ((unsigned long long)(q >> 1) * 2 * p.ct_W + (q & 1)) * p.ct_C + co;
 }
 
-template <int BM>
-__global__ __launch_bounds__(256) void k_igemm(const IGemmArgs p) {
-    constexpr int AR = BM / 32;  // float4 A loads per thread and chunk
+__device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias, int m, int n, int img) {
+    v += bias;
+    if (p.res) v += p.res[(size_t)m * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.tbias) v += p.tbias[(size_t)img * p.tb_stride + n];
+    return v;
+}
+
+template <int BM, int KW, int AMODE>
+__global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
+    constexpr int T = 256 * KW;
+    constexpr int BK = (KW == 4) ? 64 : 32;
+    constexpr int LDK = BK + 4;
+    constexpr int TPR = BK / 4;        // threads per staged row
+    constexpr int SWEEP = T / TPR;     // rows staged per sweep
+    constexpr int AR = BM / SWEEP;     // float4 A loads per thread and chunk
+    constexpr int BR = BN / SWEEP;     // float4 B loads per thread and chunk
     constexpr int NT = (BM == 128) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK + 2 * BM];
+    constexpr int KB = BK / 8;         // 8-deep k-blocks per chunk
+    static_assert(AR >= 1 && BR >= 1, "tile/threads mismatch");
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * LDK;
+    constexpr int RED_FLOATS = (KW - 1) * 4 * NT * 16 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS];
+    __shared__ unsigned long long rowOff[BM];
+    __shared__ int rowImg[BM];
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * BM * LDK;
-    float* const rowMean = smem + 2 * (BM + BN) * LDK;
-    float* const rowRstd = rowMean + BM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int tw = wave & 3;    // which output sub-tile
+    const int kpart = wave >> 2;  // which k-blocks of every chunk
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int row0 = (BM == 128) ? wave * 32 : (wave >> 1) * 32;
-    const int col0 = (BM == 128) ? 0 : (wave & 1) * 32;
+    const int row0 = (BM == 128) ? tw * 32 : (tw >> 1) * 32;
+    const int col0 = (BM == 128) ? 0 : (tw & 1) * 32;
 
     const int total_chunks = p.K / BK;
     int c_begin = 0, c_end = total_chunks;
     if (p.ksplit > 1) {
-        c_begin = blockIdx.z * p.chunks_per_split;
-        c_end = min(total_chunks, c_begin + p.chunks_per_split);
+        const int cps = p.chunks_per_split * 32 / BK;  // the host counts 32-deep chunks
+        c_begin = blockIdx.z * cps;
+        c_end = min(total_chunks, c_begin + cps);
+    }
+
+    // ---- output row table (one or two integer divisions per row, done once per block)
+    if (tid < BM) {
+        const int m = min(m0 + tid, p.M - 1);
+        int img;
+        rowOff[tid] = row_offset(p, m, img);
+        rowImg[tid] = img;
     }
 
     // ---- per-thread staging geometry
-    const int lrow = tid >> 3;  // + 32*j
-    const int c4 = (tid & 7) * 4;
-    int rb[AR], riy[AR], rix[AR];
+    const int lrow = tid / TPR;  // + SWEEP*j
+    const int c4 = (tid % TPR) * 4;
+    // Row j of this thread: 32-bit element offsets (every tensor of the network is < 2^31 elements).
+    //   conv : abase = offset of tap (0,0) of the row's window (may point before the row's image for
+    //          padded taps: only used when the tap is in bounds); asafe = the window's centre pixel
+    //          (always in bounds), read instead of an out-of-bounds tap and then zeroed
+    //   gemm : abase = m*lda + c4
+    int rb[AR], riy[AR], rix[AR], rm[AR], abase[AR], asafe[AR], nbase[AR];
     bool rvalid[AR];
     float rmean[AR], rrstd[AR];
     const int howo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        const int m = m0 + lrow + 32 * j;
+        const int m = m0 + lrow + SWEEP * j;
         rvalid[j] = m < p.M;
+        rm[j] = min(m, p.M - 1);
         rmean[j] = 0.f;
         rrstd[j] = 1.f;
-        if (p.a_mode != A_GEMM) {
-            const int mm = rvalid[j] ? m : 0;
-            const int b = mm / howo;
-            const int r = mm - b * howo;
+        rb[j] = 0;
+        riy[j] = 0;
+        rix[j] = 0;
+        abase[j] = rm[j] * p.lda + c4;
+        asafe[j] = abase[j];
+        nbase[j] = 0;
+        if (AMODE != A_GEMM) {
+            const int b = rm[j] / howo;
+            const int r = rm[j] - b * howo;
             const int oy = r / p.Wo;
             const int ox = r - oy * p.Wo;
             rb[j] = b;
             riy[j] = oy * p.stride - p.pad;
             rix[j] = ox * p.stride - p.pad;
-        } else {
-            rb[j] = 0;
-            riy[j] = 0;
-            rix[j] = 0;
+            abase[j] = ((b * p.Hi + riy[j]) * p.Wi + rix[j]) * p.Cin + c4;
+            asafe[j] = ((b * p.Hi + riy[j] + p.pad) * p.Wi + rix[j] + p.pad) * p.Cin + c4;
+            nbase[j] = b * p.Cin + c4;
         }
     }
+    int wbase[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) wbase[j] = (n0 + lrow + SWEEP * j) * p.K + c4;
 
-    // ---- LayerNorm statistics of this block's rows (two-pass, fp32), K = channel count
+    // ---- LayerNorm statistics of this thread's rows (two-pass, fp32) over the whole K = channel
+    //      count: TPR lanes share a row, same thread->row mapping as the staging loads
     if (p.ln) {
-        for (int r = wave * (BM / 4); r < (wave + 1) * (BM / 4); ++r) {
-            const int m = m0 + r;
-            float mean = 0.f, rstd = 1.f;
-            if (m < p.M) {
-                const float* src = p.A + (size_t)m * p.lda;
-                float s = 0.f;
-                for (int k = lane; k < p.K; k += 64) s += src[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                mean = s / (float)p.K;
-                float q = 0.f;
-                for (int k = lane; k < p.K; k += 64) {
-                    const float d = src[k] - mean;
-                    q += d * d;
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-                rstd = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
-            }
-            if (lane == 0) {
-                rowMean[r] = mean;
-                rowRstd[r] = rstd;
-            }
-        }
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            rmean[j] = rowMean[lrow + 32 * j];
-            rrstd[j] = rowRstd[lrow + 32 * j];
+            const float* src = p.A + abase[j];
+            float s = 0.f;
+            for (int k = 0; k < p.K; k += BK) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)p.K;
+            float q = 0.f;
+            for (int k = 0; k < p.K; k += BK) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k);
+                const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o);
+            rmean[j] = mean;
+            rrstd[j] = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
         }
     }
-
-    float4 areg[AR], breg[2];
-
-    auto load_chunk = [&](int kc) {
-        const int k0 = kc * BK;
-        if (p.a_mode == A_GEMM) {
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rvalid[j]) {
-                    v = *reinterpret_cast<const float4*>(p.A + (size_t)(m0 + lrow + 32 * j) * p.lda + k0 + c4);
-                    if (p.ln) {
-                        v.x = (v.x - rmean[j]) * rrstd[j];
-                        v.y = (v.y - rmean[j]) * rrstd[j];
-                        v.z = (v.z - rmean[j]) * rrstd[j];
-                        v.w = (v.w - rmean[j]) * rrstd[j];
-                    }
-                }
-                areg[j] = v;
-            }
-        } else if (p.a_mode == A_CONV) {
-            const int tap = k0 / p.Cin;
-            const int cc = k0 - tap * p.Cin + c4;
-            const int kh = tap / p.KW;
-            const int kw = tap - kh * p.KW;
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int iy = riy[j] + kh, ix = rix[j] + kw;
-                if (rvalid[j] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
-                    v = *reinterpret_cast<const float4*>(p.A + ((size_t)(rb[j] * p.Hi + iy) * p.Wi + ix) * p.Cin + cc);
-                    if (p.nmean) {
-                        const float4 mu = *reinterpret_cast<const float4*>(p.nmean + (size_t)rb[j] * p.Cin + cc);
-                        const float4 rs = *reinterpret_cast<const float4*>(p.nrstd + (size_t)rb[j] * p.Cin + cc);
-                        v.x = (v.x - mu.x) * rs.x;
-                        v.y = (v.y - mu.y) * rs.y;
-                        v.z = (v.z - mu.z) * rs.z;
-                        v.w = (v.w - mu.w) * rs.w;
-                    }
-                }
-                areg[j] = v;
-            }
-        } else {  // A_CONV1: k = (plane, kh, kw); a 32-chunk = one plane, four kernel rows, eight columns
-            const int plane = k0 / (p.KH * p.KW);
-            const int kh = (k0 - plane * p.KH * p.KW) / p.KW + (c4 >> 3);
-            const int kw = c4 & 7;
-            const float* src = p.planes[plane];
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                const int iy = riy[j] + kh;
-                if (rvalid[j] && iy >= 0 && iy < p.Hi) {
-                    const float* rowp = src + ((size_t)rb[j] * p.Hi + iy) * p.Wi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ix = rix[j] + kw + q;
-                        if (ix >= 0 && ix < p.Wi) e[q] = rowp[ix];
-                    }
-                }
-                areg[j] = make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            breg[j] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + lrow + 32 * j) * p.K + k0 + c4);
-    };
-
-    auto store_chunk = [&](int buf) {
-        float* As = As0 + buf * BM * LDK;
-        float* Bs = Bs0 + buf * BN * LDK;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) *reinterpret_cast<float4*>(As + (lrow + 32 * j) * LDK + c4) = areg[j];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(Bs + (lrow + 32 * j) * LDK + c4) = breg[j];
-    };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -219,79 +185,239 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemmArgs p) {
     const int fr = lane & 31;
     const int fh = (lane >> 5) * 4;
 
-    if (c_begin < c_end) {
-        load_chunk(c_begin);
-        store_chunk(0);
+    // Iteration `it` loads chunk c_begin+it into registers, multiplies chunk c_begin+it-1 from LDS
+    // buffer (it-1)&1 meanwhile, then writes the registers to buffer it&1.  One load site and one
+    // store site, so the staging registers stay in VGPRs; the final iteration's (clamped) reload is
+    // redundant by design: it keeps every load unconditional.
+    const int n_chunks = c_end - c_begin;
+    // conv: (kh, kw, cc) of the chunk being loaded, advanced incrementally (wave-uniform scalars)
+    int t_kh = 0, t_kw = 0, t_cc = 0;
+    if (AMODE == A_CONV) {
+        const int k0 = c_begin * BK;
+        const int tap = k0 / p.Cin;
+        t_cc = k0 - tap * p.Cin;
+        t_kh = tap / p.KW;
+        t_kw = tap - t_kh * p.KW;
     }
-    __syncthreads();
-    for (int kc = c_begin; kc < c_end; ++kc) {
-        const int buf = (kc - c_begin) & 1;
-        if (kc + 1 < c_end) load_chunk(kc + 1);
-        const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
-        const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
+    for (int it = 0; it <= n_chunks; ++it) {
+        const int k0 = (p.debug & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;
+        // -- load phase: issue global loads only; nothing here may consume a loaded value
+        float4 araw[AR], amu[AR], ars[AR], breg[BR];
+        unsigned okmask = 0;  // 4 bits per staged row: which of the four elements are real data
+        if (AMODE == A_GEMM) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const float4 a = *reinterpret_cast<const float4*>(As + kb * 8);
-            float4 b[NT];
+            for (int j = 0; j < AR; ++j) {
+                araw[j] = *reinterpret_cast<const float4*>(p.A + abase[j] + k0);
+                okmask |= (rvalid[j] ? 0xFu : 0u) << (4 * j);
+            }
+        } else if (AMODE == A_CONV) {
+            const int delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = rvalid[j] && (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi &&
+                                (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
+                const int off = ok ? abase[j] + delta : asafe[j] + t_cc;
+                araw[j] = *reinterpret_cast<const float4*>(p.A + off);
+                okmask |= (ok ? 0xFu : 0u) << (4 * j);
+            }
+            if (p.nmean) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                for (int j = 0; j < AR; ++j) {
+                    amu[j] = *reinterpret_cast<const float4*>(p.nmean + nbase[j] + t_cc);
+                    ars[j] = *reinterpret_cast<const float4*>(p.nrstd + nbase[j] + t_cc);
+                }
+            }
+            if (it + 1 < n_chunks && !(p.debug & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
+                t_cc += BK;
+                if (t_cc >= p.Cin) {
+                    t_cc = 0;
+                    if (++t_kw == p.KW) {
+                        t_kw = 0;
+                        ++t_kh;
+                    }
+                }
+            }
+        } else {  // A_CONV1: k = (plane, kh, kw) with an 8x8 kernel: a chunk is BK/8 kernel rows of one plane
+            const int plane = k0 >> 6;
+            const int kh = ((k0 & 63) >> 3) + (c4 >> 3);
+            const int kw = c4 & 7;
+            const float* src = plane == 0 ? p.planes[0] : plane == 1 ? p.planes[1] : plane == 2 ? p.planes[2] : p.planes[3];
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const int iy = riy[j] + kh;
+                const bool rowok = rvalid[j] && iy >= 0 && iy < p.Hi;
+                const float* rowp = src + (rb[j] * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi;
+                const int ix0 = rix[j] + kw;
+                araw[j].x = rowp[min(max(ix0, 0), p.Wi - 1)];
+                araw[j].y = rowp[min(max(ix0 + 1, 0), p.Wi - 1)];
+                araw[j].z = rowp[min(max(ix0 + 2, 0), p.Wi - 1)];
+                araw[j].w = rowp[min(max(ix0 + 3, 0), p.Wi - 1)];
+                unsigned m4 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m4 |= (rowok && ix0 + q >= 0 && ix0 + q < p.Wi) ? (1u << q) : 0u;
+                okmask |= m4 << (4 * j);
             }
         }
-        if (kc + 1 < c_end) store_chunk(buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + wbase[j] + k0);
+
+        // keep the scheduler from hoisting the store phase's ALU (and with it the wait for the loads)
+        // above the matrix work
+        __builtin_amdgcn_sched_barrier(0);
+        if (it > 0 && !(p.debug & 2)) {
+            const int buf = (it - 1) & 1;
+            const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
+            const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
+#pragma unroll
+            for (int kbi = 0; kbi < KB / KW; ++kbi) {
+                const int kb = kpart + kbi * KW;
+                const float4 a = *reinterpret_cast<const float4*>(As + kb * 8);
+                float4 b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.debug & 4) || it == 0) {   // -- store phase: normalise / zero-fill the staged operand, then write it to LDS
+            float* As = As0 + (it & 1) * BM * LDK;
+            float* Bs = Bs0 + (it & 1) * BN * LDK;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                float4 v = araw[j];
+                if (AMODE == A_GEMM && p.ln) {
+                    v.x = (v.x - rmean[j]) * rrstd[j];
+                    v.y = (v.y - rmean[j]) * rrstd[j];
+                    v.z = (v.z - rmean[j]) * rrstd[j];
+                    v.w = (v.w - rmean[j]) * rrstd[j];
+                }
+                if (AMODE == A_CONV && p.nmean) {
+                    v.x = (v.x - amu[j].x) * ars[j].x;
+                    v.y = (v.y - amu[j].y) * ars[j].y;
+                    v.z = (v.z - amu[j].z) * ars[j].z;
+                    v.w = (v.w - amu[j].w) * ars[j].w;
+                }
+                const unsigned m4 = okmask >> (4 * j);
+                v.x = (m4 & 1u) ? v.x : 0.f;
+                v.y = (m4 & 2u) ? v.y : 0.f;
+                v.z = (m4 & 4u) ? v.z : 0.f;
+                v.w = (m4 & 8u) ? v.w : 0.f;
+                *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
+        }
+        if (!(p.debug & 4) || it == 0) __syncthreads();
+    }
+
+    // ---- sum the KW partial accumulators (fixed order: k-part 0, 1, 2, 3)
+    if (KW > 1) {
+        // the trailing __syncthreads() of the loop has retired every read of the staging buffers
+        float* red = smem;
+        if (kpart > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((((kpart - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
         __syncthreads();
+        if (kpart > 0) return;
+#pragma unroll
+        for (int kp = 1; kp < KW; ++kp)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((((kp - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane];
     }
 
     // ---- epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    int ncol[NT];
+    float nbias[NT];
+    unsigned long long ncoff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int n = n0 + col0 + t * 32 + fr;
+        ncol[t] = n0 + col0 + t * 32 + fr;
+        nbias[t] = p.bias ? p.bias[ncol[t]] : 0.f;
+        ncoff[t] = col_offset(p, ncol[t]);
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + row0 + (r & 3) + 8 * (r >> 2) + fh;
-            if (m < p.M) {
-                if (p.ksplit > 1)
-                    p.partial[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[t][r];
-                else
-                    epilogue_store(p, m, n, acc[t][r]);
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + fh;
+        const int m = m0 + row;
+        if (m < p.M) {
+            if (p.ksplit > 1) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) p.partial[((size_t)blockIdx.z * p.M + m) * p.N + ncol[t]] = acc[t][r];
+            } else {
+                const unsigned long long ro = rowOff[row];
+                const int img = rowImg[row];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) p.out[ro + ncoff[t]] = finish(p, acc[t][r], nbias[t], m, ncol[t], img);
             }
         }
     }
 }
 
 // Sums the split-K slabs in slab order (bitwise reproducible) and applies the epilogue.
+// One thread per four consecutive columns of one row.
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
-    const size_t total = (size_t)p.M * p.N;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int z = 0; z < p.ksplit; ++z) v += p.partial[(size_t)z * total + idx];
+    const size_t total4 = (size_t)p.M * p.N / 4;
+    const size_t slab = (size_t)p.M * p.N;
+    for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = i4 * 4;
+        float4 v = *reinterpret_cast<const float4*>(p.partial + idx);
+        for (int z = 1; z < p.ksplit; ++z) {
+            const float4 o = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + idx);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
         const int m = (int)(idx / p.N);
         const int n = (int)(idx - (size_t)m * p.N);
-        epilogue_store(p, m, n, v);
+        int img;
+        const unsigned long long ro = row_offset(p, m, img);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float bias = p.bias ? p.bias[n + q] : 0.f;
+            p.out[ro + col_offset(p, n + q)] = finish(p, e[q], bias, m, n + q, img);
+        }
     }
 }
 
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
-    // Small problems use the 64-row tile so that more workgroups exist.
-    const bool small = ((a.M + 127) / 128) * (a.N / BN) * ks < 256;
-    if (small) {
-        dim3 grid((a.M + 63) / 64, a.N / BN, ks);
-        hipLaunchKernelGGL(k_igemm<64>, grid, dim3(256), 0, stream, a);
-    } else {
-        dim3 grid((a.M + 127) / 128, a.N / BN, ks);
-        hipLaunchKernelGGL(k_igemm<128>, grid, dim3(256), 0, stream, a);
+    int bm = a.force_bm, kw = a.force_kw;
+    if (!bm) {
+        // Enough wave-level parallelism for 256 CUs x 4 SIMDs is the first concern; operand reuse second.
+        // Measured on MI355X at batch 64 (tune_igemm): the 64-row tile beats the 128-row one on every shape of
+        // the network, 8 waves per workgroup win when there are many tiles, 16 when there are few.
+        const long t64 = (long)((a.M + 63) / 64) * (a.N / BN) * ks;
+        bm = 64;
+        kw = (t64 >= 512) ? 2 : 4;
     }
+    if (kw == 4 && (a.K % 64 || (ks > 1 && a.chunks_per_split % 2))) kw = 2;
+#define DANRA_LAUNCH_IGEMM(BM_, KW_)                                                                      \
+    do {                                                                                                  \
+        dim3 grid((a.M + BM_ - 1) / BM_, a.N / BN, ks);                                                   \
+        if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM>), grid, dim3(256 * KW_), 0, stream, a);        \
+        else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1>), grid, dim3(256 * KW_), 0, stream, a);       \
+    } while (0)
+    if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1);
+    else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4);
+    else if (kw == 2) DANRA_LAUNCH_IGEMM(64, 2);
+    else DANRA_LAUNCH_IGEMM(64, 1);
+#undef DANRA_LAUNCH_IGEMM
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ks > 1) {
-        const size_t total = (size_t)a.M * a.N;
-        int blocks = (int)((total + 255) / 256);
+        const size_t total4 = (size_t)a.M * a.N / 4;
+        int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, a);
         e = hipGetLastError();

@@ -40,20 +40,30 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
     const int per = (a.width + gridDim.y - 1) / gridDim.y;
     const int o_beg = blockIdx.y * per;
     const int o_end = min(a.width, o_beg + per);
-    for (int o = o_beg + wave; o < o_end; o += 4) {
-        const float* w = a.W + (size_t)o * a.dim;
-        const float* s = o < a.enc_width ? s_enc : s_dec;
-        float acc = 0.f;
-        for (int k = lane * 4; k < a.dim; k += 256) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + k);
-            acc = fmaf(wv.x, s[k], acc);
-            acc = fmaf(wv.y, s[k + 1], acc);
-            acc = fmaf(wv.z, s[k + 2], acc);
-            acc = fmaf(wv.w, s[k + 3], acc);
+    // Eight weight rows per wave and iteration, all loads issued before the first use (dim <= 512:
+    // at most two float4 per lane and row; the second one is masked off when dim <= 256).
+    const int k0 = min(lane * 4, a.dim - 4);
+    const int k1 = min(lane * 4 + 256, a.dim - 4);
+    const float m0 = (lane * 4 < a.dim) ? 1.f : 0.f;
+    const float m1 = (lane * 4 + 256 < a.dim) ? 1.f : 0.f;
+    for (int o = o_beg + wave * 8; o < o_end; o += 32) {
+        float4 w0[8], w1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* w = a.W + (size_t)min(o + u, o_end - 1) * a.dim;
+            w0[u] = *reinterpret_cast<const float4*>(w + k0);
+            w1[u] = *reinterpret_cast<const float4*>(w + k1);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) a.tbias[(size_t)b * a.width + o] = acc + a.b[o];
+        for (int u = 0; u < 8; ++u) {
+            const int row = min(o + u, o_end - 1);
+            const float* s = row < a.enc_width ? s_enc : s_dec;
+            float acc = m0 * ((w0[u].x * s[k0] + w0[u].y * s[k0 + 1]) + (w0[u].z * s[k0 + 2] + w0[u].w * s[k0 + 3]));
+            acc += m1 * ((w1[u].x * s[k1] + w1[u].y * s[k1 + 1]) + (w1[u].z * s[k1 + 2] + w1[u].w * s[k1 + 3]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0 && o + u < o_end) a.tbias[(size_t)b * a.width + row] = acc + a.b[row];
+        }
     }
 }
 
@@ -66,15 +76,21 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
 // InstanceNorm statistics on NHWC: block = (image, 32 channels); 8 channel quads x 32 pixel slots.
 // Two passes (mean, then centred sum of squares) so that the biased variance matches a direct
 // evaluation; the second pass re-reads from L2.
+// With gridDim.z = S > 1 the pixels are cut into S equal slices; each block then writes the mean and the
+// centred sum of squares of its slice to part[b][s][{mean, m2}][C] and k_in_stats_merge combines them
+// (Chan et al.'s pairwise update with equal counts), which keeps the two-pass accuracy.
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
-                                                  float* __restrict__ rstd, int HW, int C) {
+                                                  float* __restrict__ rstd, float* __restrict__ part, int HWtotal,
+                                                  int C) {
     __shared__ float4 red[256];
     const int b = blockIdx.x;
     const int c0 = blockIdx.y * 32;
     const int tid = threadIdx.x;
     const int cq = (tid & 7) * 4;
     const int slot = tid >> 3;
-    const float* base = x + (size_t)b * HW * C + c0 + cq;
+    const int S = gridDim.z;
+    const int HW = HWtotal / S;
+    const float* base = x + ((size_t)b * HWtotal + (size_t)blockIdx.z * HW) * C + c0 + cq;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = slot; p < HW; p += 32) {
         const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
@@ -114,18 +130,61 @@ __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, f
     }
     if (tid < 8) {
         const float4 var = red[tid];
-        float4 r;
-        r.x = 1.0f / sqrtf(var.x * inv + 1e-5f);
-        r.y = 1.0f / sqrtf(var.y * inv + 1e-5f);
-        r.z = 1.0f / sqrtf(var.z * inv + 1e-5f);
-        r.w = 1.0f / sqrtf(var.w * inv + 1e-5f);
-        *reinterpret_cast<float4*>(mean + (size_t)b * C + c0 + cq) = mu;
-        *reinterpret_cast<float4*>(rstd + (size_t)b * C + c0 + cq) = r;
+        if (S > 1) {
+            float* dst = part + (((size_t)b * S + blockIdx.z) * 2) * C + c0 + cq;
+            *reinterpret_cast<float4*>(dst) = mu;
+            *reinterpret_cast<float4*>(dst + C) = var;  // centred sum of squares of the slice
+        } else {
+            float4 r;
+            r.x = 1.0f / sqrtf(var.x * inv + 1e-5f);
+            r.y = 1.0f / sqrtf(var.y * inv + 1e-5f);
+            r.z = 1.0f / sqrtf(var.z * inv + 1e-5f);
+            r.w = 1.0f / sqrtf(var.w * inv + 1e-5f);
+            *reinterpret_cast<float4*>(mean + (size_t)b * C + c0 + cq) = mu;
+            *reinterpret_cast<float4*>(rstd + (size_t)b * C + c0 + cq) = r;
+        }
     }
 }
 
-hipError_t launch_in_stats(const float* x, float* mean, float* rstd, int B, int HW, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(k_in_stats, dim3(B, C / 32), dim3(256), 0, stream, x, mean, rstd, HW, C);
+__global__ void k_in_stats_merge(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                 int BC, int C, int S, int HWslice) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i - b * C;
+    const float* src = part + (size_t)b * S * 2 * C + c;
+    // S is a power of two <= 32; slices are loaded eight at a time so that the loads overlap
+    float ms[32], qs[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int sc = min(s, S - 1);
+        ms[s] = src[(size_t)sc * 2 * C];
+        qs[s] = src[(size_t)sc * 2 * C + C];
+    }
+    float msum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) msum += (s < S) ? ms[s] : 0.f;
+    const float mu = msum / (float)S;
+    float m2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const float d = ms[s] - mu;
+        m2 += (s < S) ? qs[s] + (float)HWslice * d * d : 0.f;
+    }
+    mean[i] = mu;
+    rstd[i] = 1.0f / sqrtf(m2 / ((float)S * (float)HWslice) + 1e-5f);
+}
+
+hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
+                           int C, hipStream_t stream) {
+    // enough blocks to fill the chip, at least 64 pixels per slice, slices of equal size
+    int S = 1;
+    while (part && S < 32 && (long)B * (C / 32) * S < 2048 && HW % (2 * S) == 0 && HW / (2 * S) >= 64 &&
+           (size_t)B * 2 * S * 2 * C <= part_floats)
+        S *= 2;
+    hipLaunchKernelGGL(k_in_stats, dim3(B, C / 32, S), dim3(256), 0, stream, x, mean, rstd, part, HW, C);
+    if (S > 1)
+        hipLaunchKernelGGL(k_in_stats_merge, dim3((B * C + 255) / 256), dim3(256), 0, stream, part, mean, rstd, B * C, C, S,
+                           HW / S);
     return hipGetLastError();
 }
 
@@ -211,8 +270,107 @@ __global__ __launch_bounds__(256) void k_final_conv(const float* __restrict__ x,
     }
 }
 
+// Matrix-core version for Cin = 64.  A block owns R output rows of one image.  Step 1: for the R+2
+// input rows it needs, G[pixel][tap] = sum_c x[pixel][c] * (w[tap][c] * rstd[c]) on the fp32 matrix
+// cores (M = 16 pixels, N = 16 >= 9 taps, K = 64; A fragments straight from global memory, 64 B per
+// pixel and lane group), results to LDS tap-major.  Step 2: every output pixel sums its nine in-bounds
+// taps of G minus the folded mean term.  The activation is read 1 + 2/R times instead of nine.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                         int W, int Cout, int R) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int P = (R + 2) * W;  // pixels of the strip incl. halo rows
+    const int PS = P + 1;       // plane stride (odd: spreads the nine planes over the banks)
+    float* Gs = sm;             // [9][PS]
+    float* wcs = sm + 9 * PS;   // [16]
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const float* xb = x + (size_t)b * H * W * 64;
+    for (int co = 0; co < Cout; ++co) {
+        // B fragments: lane (tap, g) holds w[co][tap][16s + 4g + r] * rstd[16s + 4g + r]
+        float4 bf[4];
+        float wc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = 16 * s + 4 * g;
+            const float4 wv = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + min(lq, 8)) * 64 + c);
+            const float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)b * 64 + c);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)b * 64 + c);
+            const float keep = lq < 9 ? 1.f : 0.f;
+            bf[s] = make_float4(wv.x * rs.x * keep, wv.y * rs.y * keep, wv.z * rs.z * keep, wv.w * rs.w * keep);
+            wc += (bf[s].x * mu.x + bf[s].y * mu.y) + (bf[s].z * mu.z + bf[s].w * mu.w);
+        }
+        wc += __shfl_xor(wc, 16);
+        wc += __shfl_xor(wc, 32);
+        if (wave == 0 && g == 0) wcs[lq] = wc;
+        // ---- step 1
+        const int ntiles = P / 16;
+        for (int t = wave; t < ntiles; t += 4) {
+            const int p0 = t * 16;
+            const int ry = p0 / W;
+            const int y = y0 - 1 + ry;
+            if (y < 0 || y >= H) continue;  // wave-uniform
+            const float* px = xb + ((size_t)y * W + (p0 - ry * W) + lq) * 64 + 4 * g;
+            float4 af[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[s] = *reinterpret_cast<const float4*>(px + 16 * s);
+            f32x4m acc = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].x, bf[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].y, bf[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].z, bf[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].w, bf[s].w, acc, 0, 0, 0);
+            }
+            if (lq < 9) {  // C/D layout: column = tap = lane & 15, row = pixel = 4g + reg
+                float* dst = Gs + lq * PS + p0 + 4 * g;
+                dst[0] = acc[0];
+                dst[1] = acc[1];
+                dst[2] = acc[2];
+                dst[3] = acc[3];
+            }
+        }
+        __syncthreads();
+        // ---- step 2
+        const float bco = bias ? bias[co] : 0.f;
+        for (int q = tid; q < R * W; q += 256) {
+            const int ry = q / W, ox = q - ry * W;
+            const int oy = y0 + ry;
+            float acc = bco;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                const int iy = oy + dy - 1, ix = ox + dx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc += Gs[tap * PS + (ry + dy) * W + ix] - wcs[tap];
+            }
+            out[((size_t)b * Cout + co) * H * W + (size_t)oy * W + ox] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
                              float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+    if (Cin == 64 && W % 16 == 0) {
+        int R = 8;
+        while (R > 1 && ((R + 2) * W > 1770 || H % R)) R /= 2;
+        if ((R + 2) * W <= 1770 && H % R == 0) {
+            const size_t lds2 = (9 * ((size_t)(R + 2) * W + 1) + 16) * sizeof(float);
+            if (lds2 > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_conv_mfma),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(k_final_conv_mfma, dim3(H / R, B), dim3(256), lds2, stream, x, mean, rstd, w, bias, out, H, W,
+                               Cout, R);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = ((size_t)Cout * 9 * Cin + Cout * 9) * sizeof(float);
     hipLaunchKernelGGL(k_final_conv, dim3((H * W + 255) / 256, B), dim3(256), lds, stream, x, mean, rstd, w, bias, out,
                        H, W, Cin, Cout);
