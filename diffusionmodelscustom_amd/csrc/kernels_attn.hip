@@ -17,6 +17,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int QT = 2;    // 16-query tiles per wave
 static constexpr int KVT = 64;  // keys per LDS tile
 static constexpr int KROW = 20; // padded LDS row (floats) of a 16-float K/V row: conflict-free b32 column reads
+static constexpr float RESCALE_LOG2 = 24.f;  // move the softmax reference when a score exceeds it by 2^24
+
+// Becomes one v_max3_f32: this file is compiled with -fno-honor-nans, otherwise fmaxf adds a
+// canonicalising v_max per operand that comes out of an MFMA.  (Not inline asm: the compiler does not
+// insert the MFMA-result wait states in front of an asm statement.)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
@@ -34,16 +40,28 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const float* Vb = V + (size_t)bh * L * 16;
 
     // Q fragments: B operand of S^T = K Q^T: lane (q, g) holds Q[q][4g + r] for MFMA step r.
+    // Q is pre-multiplied by hd^-1/2 * log2(e): scores come out of the matrix cores in the exp2 domain.
     float4 qf[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+    for (int t = 0; t < QT; ++t) {
+        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+        qf[t].x *= scale_log2e;
+        qf[t].y *= scale_log2e;
+        qf[t].z *= scale_log2e;
+        qf[t].w *= scale_log2e;
+    }
 
+    // Online softmax with a lazily updated reference: mref[t] is subtracted from the scores by loading
+    // -mref into the accumulators before the QK^T products, so the common case needs no per-score
+    // arithmetic before exp2.  The reference moves only on the first tile (to that tile's row maximum)
+    // and when a score exceeds it by more than 2^RESCALE_LOG2 (fp32 has the headroom: probabilities
+    // are then at most 2^24 relative to the reference and sums over 4096 keys stay far below 2^127).
     f32x4 ot[QT];
-    float mrun[QT], lrun[QT];
+    float mref[QT], lrun[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         ot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mrun[t] = -INFINITY;
+        mref[t] = 0.f;
         lrun[t] = 0.f;
     }
 
@@ -70,7 +88,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][(j * 16 + lq) * KROW + 4 * g]);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 a = f32x4{-mref[t], -mref[t], -mref[t], -mref[t]};
                 a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
@@ -79,31 +97,52 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             }
         }
         // ---- online softmax (per query = per lane & 15; the four lanes g = 0..3 share a query)
+        float mx[QT];
+        bool move = (kt == 0);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = s[t][0][0];
+            float m01 = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
+            float m23 = max3f(s[t][0][3], s[t][1][0], s[t][1][1]);
+            float m45 = max3f(s[t][1][2], s[t][1][3], s[t][2][0]);
+            float m67 = max3f(s[t][2][1], s[t][2][2], s[t][2][3]);
+            float m89 = max3f(s[t][3][0], s[t][3][1], s[t][3][2]);
+            m01 = max3f(m01, m23, s[t][3][3]);
+            m45 = max3f(m45, m67, m89);
+            mx[t] = fmaxf(m01, m45);  // lane-local maximum of (score - reference)
+            move = move || (mx[t] > RESCALE_LOG2);
+        }
+        if (__any(move)) {  // wave-uniform; first tile, then only if a score runs away from the reference
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int t = 0; t < QT; ++t) {
+                float m = mx[t];
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));  // the four lanes that share a query agree on the shift
+                const float delta = (kt == 0) ? m : ((m > RESCALE_LOG2) ? m : 0.f);
+                const float alpha = (kt == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                mref[t] += delta;
+                lrun[t] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][j][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[t], mx);
-            const float mc = mnew * scale_log2e;
-            const float alpha = exp2f(mrun[t] * scale_log2e - mc);  // exp2(-inf) = 0 on the first tile
-            mrun[t] = mnew;
-            float psum = 0.f;
+                for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f(fmaf(s[t][j][r], scale_log2e, -mc));
-                    s[t][j][r] = pv;
-                    psum += pv;
-                }
-            lrun[t] = lrun[t] * alpha + psum;
+                    for (int r = 0; r < 4; ++r) s[t][j][r] -= delta;
+            }
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
+        for (int t = 0; t < QT; ++t) {
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = __builtin_amdgcn_exp2f(s[t][j][0]);
+                const float p1 = __builtin_amdgcn_exp2f(s[t][j][1]);
+                const float p2 = __builtin_amdgcn_exp2f(s[t][j][2]);
+                const float p3 = __builtin_amdgcn_exp2f(s[t][j][3]);
+                s[t][j] = f32x4{p0, p1, p2, p3};
+                ps0 += p0 + p2;
+                ps1 += p1 + p3;
+            }
+            lrun[t] += ps0 + ps1;
         }
         // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[16j + 4g + r][d]), B = P (the S^T registers)
 #pragma unroll
