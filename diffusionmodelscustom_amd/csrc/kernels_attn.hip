@@ -14,7 +14,7 @@ namespace danra {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int QT = 2;    // 16-query tiles per wave
+// QT = 16-query tiles per wave (template parameter of k_flash_hd16)
 static constexpr int KVT = 64;  // keys per LDS tile
 static constexpr int KROW = 20; // padded LDS row (floats) of a 16-float K/V row: conflict-free b32 column reads
 static constexpr float RESCALE_LOG2 = 24.f;  // move the softmax reference when a score exceeds it by 2^24
@@ -24,6 +24,7 @@ static constexpr float RESCALE_LOG2 = 24.f;  // move the softmax reference when 
 // insert the MFMA-result wait states in front of an asm statement.)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+template <int QT>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     int L, int heads, float scale_log2e) {
@@ -81,80 +82,82 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
             vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * KVT + srow) * 16 + sc4);
         }
-        // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 16j + 4g + r)
-        f32x4 s[QT][4];
+        // The 64-key tile is consumed in two halves of 32 keys (QK^T -> softmax -> PV each), which keeps
+        // the live score registers at 8 per query tile.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][(j * 16 + lq) * KROW + 4 * g]);
+        for (int hf = 0; hf < 2; ++hf) {
+            // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 32hf + 16j + 4g + r) - reference
+            f32x4 s[QT][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 a = f32x4{-mref[t], -mref[t], -mref[t], -mref[t]};
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
+                    s[t][j] = a;
+                }
+            }
+            // ---- online softmax (per query = per lane & 15; the four lanes g = 0..3 share a query)
+            float mx[QT];
+            const bool first = (kt == 0 && hf == 0);
+            bool move = first;
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                f32x4 a = f32x4{-mref[t], -mref[t], -mref[t], -mref[t]};
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
-                s[t][j] = a;
+                const float m0 = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
+                const float m1 = max3f(s[t][0][3], s[t][1][0], s[t][1][1]);
+                const float m2 = max3f(s[t][1][2], s[t][1][3], m0);
+                mx[t] = fmaxf(m1, m2);  // lane-local maximum of (score - reference)
+                move = move || (mx[t] > RESCALE_LOG2);
             }
-        }
-        // ---- online softmax (per query = per lane & 15; the four lanes g = 0..3 share a query)
-        float mx[QT];
-        bool move = (kt == 0);
+            if (__any(move)) {  // wave-uniform; first step, then only if a score runs away from the reference
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float m01 = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
-            float m23 = max3f(s[t][0][3], s[t][1][0], s[t][1][1]);
-            float m45 = max3f(s[t][1][2], s[t][1][3], s[t][2][0]);
-            float m67 = max3f(s[t][2][1], s[t][2][2], s[t][2][3]);
-            float m89 = max3f(s[t][3][0], s[t][3][1], s[t][3][2]);
-            m01 = max3f(m01, m23, s[t][3][3]);
-            m45 = max3f(m45, m67, m89);
-            mx[t] = fmaxf(m01, m45);  // lane-local maximum of (score - reference)
-            move = move || (mx[t] > RESCALE_LOG2);
-        }
-        if (__any(move)) {  // wave-uniform; first tile, then only if a score runs away from the reference
+                for (int t = 0; t < QT; ++t) {
+                    float m = mx[t];
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));  // the four lanes that share a query agree on the shift
+                    const float delta = first ? m : ((m > RESCALE_LOG2) ? m : 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                    mref[t] += delta;
+                    lrun[t] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[t][j][r] -= delta;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                float m = mx[t];
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));  // the four lanes that share a query agree on the shift
-                const float delta = (kt == 0) ? m : ((m > RESCALE_LOG2) ? m : 0.f);
-                const float alpha = (kt == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                mref[t] += delta;
-                lrun[t] *= alpha;
+                float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[t][j][r] -= delta;
+                for (int j = 0; j < 2; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[t][j][0]);
+                    const float p1 = __builtin_amdgcn_exp2f(s[t][j][1]);
+                    const float p2 = __builtin_amdgcn_exp2f(s[t][j][2]);
+                    const float p3 = __builtin_amdgcn_exp2f(s[t][j][3]);
+                    s[t][j] = f32x4{p0, p1, p2, p3};
+                    ps0 += p0 + p2;
+                    ps1 += p1 + p3;
+                }
+                lrun[t] += ps0 + ps1;
             }
-        }
+            // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[key 4g + r][d]), B = P (the S^T registers)
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float ps0 = 0.f, ps1 = 0.f;
+            for (int j = 0; j < 2; ++j) {
+                float vf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float p0 = __builtin_amdgcn_exp2f(s[t][j][0]);
-                const float p1 = __builtin_amdgcn_exp2f(s[t][j][1]);
-                const float p2 = __builtin_amdgcn_exp2f(s[t][j][2]);
-                const float p3 = __builtin_amdgcn_exp2f(s[t][j][3]);
-                s[t][j] = f32x4{p0, p1, p2, p3};
-                ps0 += p0 + p2;
-                ps1 += p1 + p3;
+                for (int r = 0; r < 4; ++r) vf[r] = Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq];
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
             }
-            lrun[t] += ps0 + ps1;
-        }
-        // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[16j + 4g + r][d]), B = P (the S^T registers)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float vf[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vf[r] = Vs[buf][(j * 16 + 4 * g + r) * KROW + lq];
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
         }
         *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
         *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
@@ -238,7 +241,7 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
     if (hd == 16 && L % 128 == 0) {
         const float scale_log2e = 0.25f * 1.4426950408889634f;
         dim3 grid(L / 128, B * heads);
-        hipLaunchKernelGGL(k_flash_hd16, grid, dim3(256), 0, stream, q, k, v, out, L, heads, scale_log2e);
+        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, scale_log2e);
         return hipGetLastError();
     }
     const size_t lds = ((size_t)L * (hd + 1) + (size_t)L * hd + 4 * (size_t)L + 4 * (size_t)hd) * sizeof(float);
