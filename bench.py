@@ -80,10 +80,12 @@ def build_model(w, seed):
     return fill_state_dict_(model, seed).eval()
 
 
-def cpu_baseline(w, n_steps=4, batch=8):
+def cpu_baseline(w, n_steps=25, batch=None):
     """The CPU restatement (oracle/cpu_ref.py, parity-pinned to the reference) on the host cores: `n_steps`
-    denoise steps (UNet + update) at a reduced batch after one warm-up step, extrapolated to T-1 steps."""
+    denoise steps (UNet + update) at the workload's batch after one warm-up step (about 10-20 s of CPU work),
+    extrapolated to T-1 steps."""
     from oracle import cpu_ref
+    batch = batch or w["batch"]
     model = build_model(w, 42)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     inp = synthetic_inputs(batch, w["size"], w["size"], seed=42, conditional=w["cond"])
