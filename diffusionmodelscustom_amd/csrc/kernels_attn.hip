@@ -24,15 +24,29 @@ static constexpr float RESCALE_LOG2 = 24.f;  // move the softmax reference when 
 // insert the MFMA-result wait states in front of an asm statement.)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int QT>
+// ABL: timing ablations for tune_flash (results are wrong unless 0): 1 = no exp2, 2 = no V reads from LDS,
+// 4 = no staging/barrier after the first tile, 8 = no QK^T MFMAs, 16 = no PV MFMAs.
+template <int QT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
-                                                    int L, int heads, float scale_log2e) {
+                                                    int L, int heads, int n_bh, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) float Ks[2][KVT * KROW];
     __shared__ __attribute__((aligned(16))) float Vs[2][KVT * KROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
+    // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group).  The linear id is
+    // decoded as (bh / 8, query block, bh % 8), so every query block of one (image, head) pair runs on the
+    // same XCD and its K/V rows are fetched into one L2 instead of eight.  (Speed only.)
+    const int nq = L / (4 * QT * 16);
+    int bh, qblk;
+    if (n_bh % 8 == 0) {
+        const int id = blockIdx.x;
+        bh = (id / (8 * nq)) * 8 + (id & 7);
+        qblk = (id >> 3) % nq;
+    } else {
+        bh = blockIdx.x / nq;
+        qblk = blockIdx.x - bh * nq;
+    }
+    const int q0 = qblk * (4 * QT * 16) + wave * (QT * 16);
     const int lq = lane & 15;  // query column / key row / d column, depending on the operand
     const int g = lane >> 4;   // k-slot of the MFMA
 
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
 
     const int ntiles = L / KVT;
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
+        const int buf = (ABL & 4) ? 0 : (kt & 1);
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
             kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
@@ -94,10 +108,14 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     f32x4 a = f32x4{-mref[t], -mref[t], -mref[t], -mref[t]};
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
+                    if (!(ABL & 8)) {
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
+                    } else {
+                        a[0] += kf.x * qf[t].x; a[1] += kf.y; a[2] += kf.z; a[3] += kf.w;
+                    }
                     s[t][j] = a;
                 }
             }
@@ -136,10 +154,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float p0 = __builtin_amdgcn_exp2f(s[t][j][0]);
-                    const float p1 = __builtin_amdgcn_exp2f(s[t][j][1]);
-                    const float p2 = __builtin_amdgcn_exp2f(s[t][j][2]);
-                    const float p3 = __builtin_amdgcn_exp2f(s[t][j][3]);
+                    const float p0 = (ABL & 1) ? s[t][j][0] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][0]);
+                    const float p1 = (ABL & 1) ? s[t][j][1] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][1]);
+                    const float p2 = (ABL & 1) ? s[t][j][2] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][2]);
+                    const float p3 = (ABL & 1) ? s[t][j][3] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][3]);
                     s[t][j] = f32x4{p0, p1, p2, p3};
                     ps0 += p0 + p2;
                     ps1 += p1 + p3;
@@ -151,17 +169,22 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             for (int j = 0; j < 2; ++j) {
                 float vf[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vf[r] = Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq];
+                for (int r = 0; r < 4; ++r)
+                    vf[r] = (ABL & 2) ? qf[0].x + (float)r : Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq];
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        if (!(ABL & 16)) ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t], 0, 0, 0);
+                        else ot[t][r] += vf[r] * s[t][j][r];
+                    }
             }
         }
-        *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
-        *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
-        __syncthreads();
+        if (!(ABL & 4)) {
+            *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
+            *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
+            __syncthreads();
+        }
     }
 
     // ---- normalise and store: lane (q, g) holds O[q][4g + r], r = 0..3
@@ -240,8 +263,8 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
                             int hd, hipStream_t stream) {
     if (hd == 16 && L % 128 == 0) {
         const float scale_log2e = 0.25f * 1.4426950408889634f;
-        dim3 grid(L / 128, B * heads);
-        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, scale_log2e);
+        dim3 grid((L / 128) * B * heads);
+        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, B * heads, scale_log2e);
         return hipGetLastError();
     }
     const size_t lds = ((size_t)L * (hd + 1) + (size_t)L * hd + 4 * (size_t)L + 4 * (size_t)hd) * sizeof(float);

@@ -1,0 +1,54 @@
+// Developer tool (not part of libdanra_hip.so): times the head_dim-16 flash attention kernel and its
+// timing ablations (see the ABL template parameter) with HIP events on random data.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels_attn.hip"
+
+using namespace danra;
+
+template <int ABL>
+static void run(const char* name, const float* q, const float* k, const float* v, float* o, int B, int L) {
+    const int heads = 4;
+    const float sc = 0.25f * 1.4426950408889634f;
+    dim3 grid((L / 128) * B * heads);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, L, heads, B * heads, sc);
+    hipEventRecord(e0, 0);
+    const int iters = 10;
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, L, heads, B * heads, sc);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / iters;
+    const double fl = 4.0 * B * heads * (double)L * L * 16;
+    printf("%-34s %8.1f us  %6.1f TF/s (nominal)\n", name, us, fl / us / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64, L = argc > 2 ? atoi(argv[2]) : 1024;
+    const size_t n = (size_t)B * L * 64;
+    float *q, *k, *v, *o;
+    hipMalloc(&q, n * 4); hipMalloc(&k, n * 4); hipMalloc(&v, n * 4); hipMalloc(&o, n * 4);
+    std::vector<float> h(n);
+    srand(2);
+    for (auto& x : h) x = (float)(rand() % 2001 - 1000) / 500.f;
+    hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
+    run<0>("full", q, k, v, o, B, L);
+    run<1>("no exp2", q, k, v, o, B, L);
+    run<2>("no V LDS reads", q, k, v, o, B, L);
+    run<4>("no staging/barrier", q, k, v, o, B, L);
+    run<8>("no QK^T MFMA", q, k, v, o, B, L);
+    run<16>("no PV MFMA", q, k, v, o, B, L);
+    run<24>("no MFMA at all", q, k, v, o, B, L);
+    run<7>("MFMA + max/sum only", q, k, v, o, B, L);
+    return 0;
+}
