@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -79,9 +80,18 @@ struct Workspace {
     float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
     float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part;
     size_t stats_part_floats = 0;
-    int64_t* t_i64;
     size_t partial_floats = 0;
+    // sampler: device-resident loop state, per-timestep update coefficients, private copies of the inputs
+    // (so that a captured step never refers to caller memory) and the captured step itself
+    SampleState* state;
+    float4* coef;
+    float *xs, *conds, *lsms, *topos;
+    int64_t* ys;
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
+    int step_exec_has_y = -1;
 };
+constexpr int kMaxTimesteps = 8192;  // rows of the coefficient table
 
 }  // namespace
 
@@ -112,6 +122,10 @@ struct danra_handle_s {
     std::vector<hipEvent_t> prof_events;
     size_t prof_used = 0;
     double prof_flops = 0.0;
+    // sampling loop: 1 = replay one captured denoise step (hipGraph), 0 = enqueue every kernel
+    int graph_mode = 1;
+    hipStream_t cap_stream = nullptr;
+    std::vector<float4> h_coef;
 };
 
 namespace {
@@ -327,11 +341,20 @@ int upload_freq(danra_handle_s* h, hipStream_t st) {
     return DANRA_OK;
 }
 
+void drop_step_graph(Workspace& ws) {
+    if (ws.step_exec) (void)hipGraphExecDestroy(ws.step_exec);
+    if (ws.step_graph) (void)hipGraphDestroy(ws.step_graph);
+    ws.step_exec = nullptr;
+    ws.step_graph = nullptr;
+    ws.step_exec_has_y = -1;
+}
+
 int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
     Workspace& ws = h->ws;
     if (ws.base && ws.B == B && ws.H == H && ws.W == W) return DANRA_OK;
     if (ws.base) {
         HIP_TRY(hipDeviceSynchronize());
+        drop_step_graph(ws);
         HIP_TRY(hipFree(ws.base));
         ws.base = nullptr;
     }
@@ -339,7 +362,13 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         Bump bp(pass ? ws.base : nullptr);
         const size_t hw2 = (size_t)(H / 2) * (W / 2), hw4 = (size_t)(H / 4) * (W / 4);
         ws.tbias = bp.take((size_t)B * h->tb_width);
-        ws.t_i64 = (int64_t*)bp.take((size_t)B * 2);
+        ws.state = (SampleState*)bp.take(64);
+        ws.coef = (float4*)bp.take((size_t)kMaxTimesteps * 4);
+        ws.ys = (int64_t*)bp.take((size_t)B * 2);
+        ws.xs = bp.take((size_t)B * H * W);
+        ws.conds = bp.take((size_t)B * H * W);
+        ws.lsms = bp.take((size_t)B * H * W);
+        ws.topos = bp.take((size_t)B * H * W);
         ws.f1pre = bp.take(B * hw2 * 64);
         ws.c2 = bp.take(B * hw4 * 64);
         for (int i = 0; i < 4; ++i) ws.rt[i] = bp.take(B * hw4 * 64);
@@ -518,11 +547,11 @@ int run_layer(danra_handle_s* h, int level, const float* x, float* out, int B, i
     return DANRA_OK;
 }
 
-int run_time_mlp(danra_handle_s* h, const int64_t* t, const int64_t* y, int B, float* enc_out, float* dec_out,
-                 float* tbias, hipStream_t st) {
+int run_time_mlp(danra_handle_s* h, const int64_t* t, SampleState* state, const int64_t* y, int B, float* enc_out,
+                 float* dec_out, float* tbias, hipStream_t st) {
     RC_TRY(upload_freq(h, st));
     TimeMlpArgs a;
-    a.t = t; a.y = (h->cfg.num_classes > 0) ? y : nullptr; a.label_emb = h->label_emb;
+    a.t = t; a.state = state; a.y = (h->cfg.num_classes > 0) ? y : nullptr; a.label_emb = h->label_emb;
     a.enc_inv_freq = h->enc_inv_freq; a.dec_div = h->dec_div; a.W = h->tw; a.b = h->tb;
     a.enc_emb_out = enc_out; a.dec_emb_out = dec_out; a.tbias = tbias;
     a.B = B; a.dim = h->cfg.time_embedding; a.width = h->tb_width; a.enc_width = h->enc_width;
@@ -555,10 +584,12 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
     return DANRA_OK;
 }
 
-int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, const int64_t* y, const float* cond,
-                 const float* lsm, const float* topo, float* eps, int B, int H, int W, hipStream_t st) {
+// `t` gives one timestep per image; with t == null every image uses the sampler state's current one.
+int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleState* state, const int64_t* y,
+                 const float* cond, const float* lsm, const float* topo, float* eps, int B, int H, int W,
+                 hipStream_t st) {
     Workspace& ws = h->ws;
-    RC_TRY(run_time_mlp(h, t, y, B, nullptr, nullptr, ws.tbias, st));
+    RC_TRY(run_time_mlp(h, t, state, y, B, nullptr, nullptr, ws.tbias, st));
     const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
     int np = 0;
     planes[np++] = x;
@@ -620,6 +651,7 @@ int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
     for (int k = 0; k < 4; ++k) { h->dec[k].tb_off = off; off += kFmap[3 - k]; }
     h->tb_width = off;
     build_param_table(h);
+    if (const char* g = getenv("DANRA_GRAPH")) h->graph_mode = (g[0] == '0') ? 0 : 1;
     const int half = cfg->time_embedding / 2;
     h->h_enc_inv_freq.resize(half);
     h->h_dec_div.resize(half);
@@ -635,7 +667,9 @@ int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
 int danra_destroy(danra_handle_t h) {
     if (!h) return DANRA_OK;
     if (h->arena) (void)hipFree(h->arena);
+    drop_step_graph(h->ws);
     if (h->ws.base) (void)hipFree(h->ws.base);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     delete h;
     return DANRA_OK;
@@ -700,7 +734,7 @@ int danra_unet_forward(danra_handle_t h, const float* x, const int64_t* t, const
     if (h->cfg.has_topo && !topo) return fail(DANRA_EINVAL, "topo_cond is required by this model");
     if (h->cfg.has_cond && !cond) return fail(DANRA_EINVAL, "cond_img is required by this model");
     RC_TRY(ensure_workspace(h, B, H, W));
-    return forward_impl(h, x, t, y, cond, lsm, topo, eps, B, H, W, (hipStream_t)stream);
+    return forward_impl(h, x, t, nullptr, y, cond, lsm, topo, eps, B, H, W, (hipStream_t)stream);
 }
 
 int danra_get_fmaps(danra_handle_t h, float* f1, float* f2, float* f3, float* f4, float* f5, void* stream) {
@@ -740,33 +774,72 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
     if (h->cfg.has_lsm && !lsm) return fail(DANRA_EINVAL, "lsm_cond is required by this model");
     if (h->cfg.has_topo && !topo) return fail(DANRA_EINVAL, "topo_cond is required by this model");
     if (h->cfg.has_cond && !cond) return fail(DANRA_EINVAL, "cond_img is required by this model");
+    if (T - 1 >= kMaxTimesteps) return fail(DANRA_EINVAL, "T=%d exceeds the %d-step coefficient table", T, kMaxTimesteps);
     RC_TRY(ensure_workspace(h, B, H, W));
     hipStream_t st = (hipStream_t)stream;
     Workspace& ws = h->ws;
     const size_t n = (size_t)B * H * W;
-    size_t draw = 0;
-    for (int i = T - 1; i >= 1; --i) {
-        HIP_TRY(launch_fill_i64(ws.t_i64, (int64_t)i, B, st));
-        RC_TRY(forward_impl(h, x, ws.t_i64, y, cond, lsm, topo, ws.eps, B, H, W, st));
-        // fp32 scalar arithmetic in the order of diffusion_DANRA_conditional.py:135-157
+    // Per-timestep coefficients: fp32 scalar arithmetic in the order of diffusion_DANRA_conditional.py:135-157
+    h->h_coef.assign((size_t)T, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int i = 1; i < T; ++i) {
         const float alpha = alphas[i], beta = betas[i], ah = alpha_hat[i];
         const float one_minus_alpha = 1.0f - alpha, one_minus_ah = 1.0f - ah;
-        const float c1 = 1.0f / sqrtf(alpha);
-        const float c2 = one_minus_alpha / sqrtf(one_minus_ah);
-        const float c3 = sqrtf(beta);
-        if (i > 1) {
-            if (noise_mode == DANRA_NOISE_PHILOX)
-                HIP_TRY(launch_ddpm_update(x, ws.eps, nullptr, c1, c2, c3, n, 1, seed, (uint64_t)i, st));
-            else
-                HIP_TRY(launch_ddpm_update(x, ws.eps, noise + draw * n, c1, c2, c3, n, 0, 0, 0, st));
-            ++draw;
-        } else {
-            HIP_TRY(launch_ddpm_update(x, ws.eps, nullptr, c1, c2, c3, n, 0, 0, 0, st));
+        h->h_coef[i] = make_float4(1.0f / sqrtf(alpha), one_minus_alpha / sqrtf(one_minus_ah), sqrtf(beta), 0.f);
+    }
+    HIP_TRY(hipMemcpyAsync(ws.coef, h->h_coef.data(), (size_t)T * sizeof(float4), hipMemcpyHostToDevice, st));
+    // private copies of the inputs: the step (eager or captured) only ever touches workspace memory
+    const bool has_y = (h->cfg.num_classes > 0) && y;
+    HIP_TRY(hipMemcpyAsync(ws.xs, x, n * 4, hipMemcpyDeviceToDevice, st));
+    if (has_y) HIP_TRY(hipMemcpyAsync(ws.ys, y, (size_t)B * 8, hipMemcpyDeviceToDevice, st));
+    if (h->cfg.has_cond) HIP_TRY(hipMemcpyAsync(ws.conds, cond, n * 4, hipMemcpyDeviceToDevice, st));
+    if (h->cfg.has_lsm) HIP_TRY(hipMemcpyAsync(ws.lsms, lsm, n * 4, hipMemcpyDeviceToDevice, st));
+    if (h->cfg.has_topo) HIP_TRY(hipMemcpyAsync(ws.topos, topo, n * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(launch_init_state(ws.state, T - 1, noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed,
+                              noise_mode == DANRA_NOISE_HOST ? noise : nullptr, st));
+    RC_TRY(upload_freq(h, st));
+
+    auto enqueue_step = [&](hipStream_t s) -> int {
+        RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, has_y ? ws.ys : nullptr, ws.conds, ws.lsms, ws.topos, ws.eps, B,
+                            H, W, s));
+        HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, ws.coef, ws.state, n, s));
+        return DANRA_OK;
+    };
+
+    const bool use_graph = h->graph_mode && h->prof_kind == 0;
+    if (use_graph && (!ws.step_exec || ws.step_exec_has_y != (int)has_y)) {
+        drop_step_graph(ws);
+        if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_step(h->cap_stream);
+        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &ws.step_graph);
+        if (rc != DANRA_OK) { drop_step_graph(ws); return rc; }
+        if (ce != hipSuccess) {
+            drop_step_graph(ws);
+            return fail(DANRA_EHIP, "capturing the denoise step failed: %s", hipGetErrorString(ce));
         }
+        const hipError_t ie = hipGraphInstantiate(&ws.step_exec, ws.step_graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            drop_step_graph(ws);
+            return fail(DANRA_EHIP, "instantiating the denoise-step graph failed: %s", hipGetErrorString(ie));
+        }
+        ws.step_exec_has_y = (int)has_y;
+    }
+    for (int i = T - 1; i >= 1; --i) {
+        if (use_graph)
+            HIP_TRY(hipGraphLaunch(ws.step_exec, st));
+        else
+            RC_TRY(enqueue_step(st));
         for (int k = 0; k < n_trace; ++k)
             if (trace && trace_steps && trace_steps[k] == i)
-                HIP_TRY(hipMemcpyAsync(trace + (size_t)k * n, x, n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(trace + (size_t)k * n, ws.xs, n * 4, hipMemcpyDeviceToDevice, st));
     }
+    HIP_TRY(hipMemcpyAsync(x, ws.xs, n * 4, hipMemcpyDeviceToDevice, st));
+    return DANRA_OK;
+}
+
+int danra_set_graph_mode(danra_handle_t h, int enable) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    h->graph_mode = enable ? 1 : 0;
     return DANRA_OK;
 }
 
@@ -803,7 +876,7 @@ int danra_tbias_width(danra_handle_t h) { return h ? h->tb_width : 0; }
 int danra_time_embed(danra_handle_t h, const int64_t* t, const int64_t* y, int B, float* enc, float* dec, float* tbias,
                      void* stream) {
     if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
-    return run_time_mlp(h, t, y, B, enc, dec, tbias, (hipStream_t)stream);
+    return run_time_mlp(h, t, nullptr, y, B, enc, dec, tbias, (hipStream_t)stream);
 }
 
 // The per-op entry points size the workspace for the smallest image whose buffers hold the op.
@@ -864,7 +937,7 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap, const fl
     const int cin = h->dec[block].Cin;
     RC_TRY(op_workspace(h, B, 4 * (((long)H * W * cin + 63) / 64)));
     if (!t) return fail(DANRA_EINVAL, "t is required");
-    RC_TRY(run_time_mlp(h, t, nullptr, B, nullptr, nullptr, h->ws.tbias, st));
+    RC_TRY(run_time_mlp(h, t, nullptr, nullptr, B, nullptr, nullptr, h->ws.tbias, st));
     return run_decoder_block(h, block, fmap, skip, h->ws.tbias, out, B, H, W, st);
 }
 

@@ -50,8 +50,26 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
                             int L, int hd, hipStream_t stream);
 
 // ---------------------------------------------------------------- small kernels
+// Device-resident state of the sampling loop: one denoise step can be enqueued (or replayed from a
+// hipGraph) without any per-step host argument.  k_time_mlp reads t_fwd and publishes it as t_upd; the
+// update kernel reads t_upd and publishes t_upd - 1 as t_fwd, so no kernel reads a field it writes.
+struct SampleState {
+    int t_fwd;                 // timestep of the next UNet evaluation
+    int t_upd;                 // timestep of the next update
+    int t_max;                 // T - 1: the timestep of the first draw
+    int philox;                // 1: z drawn in-kernel (Philox), 0: z read from `noise`
+    unsigned long long seed;
+    const float* noise;        // host-noise mode: [T-2][n] draws in draw order (timestep T-1 first), or null
+};
+hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
+                             hipStream_t stream);
+// x <- c1*(x - c2*eps) + c3*z with (c1, c2, c3) = coef[state->t_upd] and z = 0 at timestep 1.
+hipError_t launch_ddpm_update_state(float* x, const float* eps, const float4* coef, SampleState* state, size_t n,
+                                    hipStream_t stream);
+
 struct TimeMlpArgs {
-    const int64_t* t;
+    const int64_t* t;          // [B], or null when `state` supplies one timestep for every row
+    SampleState* state;        // may be null
     const int64_t* y;          // may be null
     const float* label_emb;    // [num_classes][dim] or null
     const float* enc_inv_freq; // [dim/2]
@@ -76,7 +94,6 @@ hipError_t launch_final_conv(const float* x, const float* mean, const float* rst
                              float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
 hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
                               size_t n, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
-hipError_t launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 

@@ -6,69 +6,110 @@
 namespace danra {
 
 // ------------------------------------------------------------------------------------------------
-// Time embeddings and the nine Sequential(SiLU, Linear(dim, C)) projections.
-// grid (B, SPLIT): every block rebuilds the two embeddings of its image (dim <= 512 values, cheap)
-// and computes its share of the projection outputs, one wave per output row.
+// Time embeddings and the nine Sequential(SiLU, Linear(dim, C)) projections:
+// tbias[b][row] = W[row] . SiLU(emb(b)) + bias[row], emb = encoder embedding (+ label embedding) for
+// rows < enc_width, decoder embedding otherwise.
+// grid = width/16 blocks of 4 waves; a block owns 16 projection rows (all encoder or all decoder rows)
+// and every image.  It stages SiLU(emb) of up to 64 images at a time in LDS as float4 groups
+// [k/4][image] (one group row = 64 float4 + 1 float4 of padding: conflict-free for both the per-k writes
+// and the per-image b128 reads), then each wave runs lanes = images over k with its 4 weight rows read
+// through wave-uniform (scalar) loads.  The sin/cos of a timestep is evaluated once per run of equal
+// timesteps (the sampler gives every image the same one).
+constexpr int TM_ROWS = 16;
+constexpr int TM_GROUP = 65;  // float4 per k-group row
+
 __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
-    __shared__ float s_enc[512];
-    __shared__ float s_dec[512];
-    const int b = blockIdx.x;
+    extern __shared__ float4 tm_s[];  // [dim/4][TM_GROUP]
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = a.dim / 2;
-    const long long ti = a.t[b];
-    const float tf = (float)ti;
-    for (int j = tid; j < a.dim; j += 256) {
-        // encoder: [sin(t*f_0..f_half-1) | cos(...)], base 1000, then + label embedding
-        const int k = j < half ? j : j - half;
-        const float arg = tf * a.enc_inv_freq[k];
-        float e = j < half ? sinf(arg) : cosf(arg);
-        if (a.y) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
-        // decoder: interleaved sin/cos of t / 10000^(2k/dim)
-        const int kd = j >> 1;
-        const float argd = tf / a.dec_div[kd];
-        const float d = (j & 1) ? cosf(argd) : sinf(argd);
-        if (blockIdx.y == 0) {
-            if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
-            if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d;
-        }
-        s_enc[j] = e / (1.0f + expf(-e));  // SiLU
-        s_dec[j] = d / (1.0f + expf(-d));
+    const int row0 = blockIdx.x * TM_ROWS;
+    const bool enc_rows = row0 < a.enc_width;
+    const bool write_emb = blockIdx.x == 0;
+    const bool dec_needed = !enc_rows || (write_emb && a.dec_emb_out);
+    const bool enc_needed = enc_rows || (write_emb && a.enc_emb_out);
+    int t_state = 0;
+    if (a.state) {
+        t_state = a.state->t_fwd;
+        if (blockIdx.x == 0 && tid == 0) a.state->t_upd = t_state;
     }
-    __syncthreads();
-    if (!a.tbias) return;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int per = (a.width + gridDim.y - 1) / gridDim.y;
-    const int o_beg = blockIdx.y * per;
-    const int o_end = min(a.width, o_beg + per);
-    // Eight weight rows per wave and iteration, all loads issued before the first use (dim <= 512:
-    // at most two float4 per lane and row; the second one is masked off when dim <= 256).
-    const int k0 = min(lane * 4, a.dim - 4);
-    const int k1 = min(lane * 4 + 256, a.dim - 4);
-    const float m0 = (lane * 4 < a.dim) ? 1.f : 0.f;
-    const float m1 = (lane * 4 + 256 < a.dim) ? 1.f : 0.f;
-    for (int o = o_beg + wave * 8; o < o_end; o += 32) {
-        float4 w0[8], w1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float* w = a.W + (size_t)min(o + u, o_end - 1) * a.dim;
-            w0[u] = *reinterpret_cast<const float4*>(w + k0);
-            w1[u] = *reinterpret_cast<const float4*>(w + k1);
+    float* s_flat = reinterpret_cast<float*>(tm_s);
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        const int nb = min(64, a.B - b0);
+        for (int j = tid; j < a.dim; j += 256) {
+            const int k = j < half ? j : j - half;
+            const float f_enc = a.enc_inv_freq[k];
+            const float f_dec = a.dec_div[j >> 1];
+            long long t_prev = -1;
+            float e_base = 0.f, d_base = 0.f;
+            for (int bb = 0; bb < nb; ++bb) {
+                const int b = b0 + bb;
+                const long long ti = a.state ? (long long)t_state : a.t[b];
+                if (bb == 0 || ti != t_prev) {
+                    const float tf = (float)ti;
+                    if (enc_needed) {
+                        // encoder: [sin(t*f_0..f_half-1) | cos(...)], base 1000
+                        const float arg = tf * f_enc;
+                        e_base = j < half ? sinf(arg) : cosf(arg);
+                    }
+                    if (dec_needed) {
+                        // decoder: interleaved sin/cos of t / 10000^(2k/dim)
+                        const float argd = tf / f_dec;
+                        d_base = (j & 1) ? cosf(argd) : sinf(argd);
+                    }
+                    t_prev = ti;
+                }
+                float e = e_base;
+                if (enc_needed && a.y) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
+                if (write_emb) {
+                    if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
+                    if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d_base;
+                }
+                const float v = enc_rows ? e : d_base;
+                s_flat[((j >> 2) * TM_GROUP + bb) * 4 + (j & 3)] = v / (1.0f + expf(-v));  // SiLU
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int row = min(o + u, o_end - 1);
-            const float* s = row < a.enc_width ? s_enc : s_dec;
-            float acc = m0 * ((w0[u].x * s[k0] + w0[u].y * s[k0 + 1]) + (w0[u].z * s[k0 + 2] + w0[u].w * s[k0 + 3]));
-            acc += m1 * ((w1[u].x * s[k1] + w1[u].y * s[k1 + 1]) + (w1[u].z * s[k1 + 2] + w1[u].w * s[k1 + 3]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-            if (lane == 0 && o + u < o_end) a.tbias[(size_t)b * a.width + row] = acc + a.b[row];
+        __syncthreads();
+        if (a.tbias) {
+            const int r = row0 + wave * 4;
+            const float* w0 = a.W + (size_t)r * a.dim;
+            const float* w1 = w0 + a.dim;
+            const float* w2 = w1 + a.dim;
+            const float* w3 = w2 + a.dim;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            for (int k4 = 0; k4 < a.dim / 4; ++k4) {
+                const float4 sv = tm_s[k4 * TM_GROUP + lane];
+                const float4 a0 = *reinterpret_cast<const float4*>(w0 + 4 * k4);
+                const float4 a1 = *reinterpret_cast<const float4*>(w1 + 4 * k4);
+                const float4 a2 = *reinterpret_cast<const float4*>(w2 + 4 * k4);
+                const float4 a3 = *reinterpret_cast<const float4*>(w3 + 4 * k4);
+                acc0 += a0.x * sv.x; acc0 += a0.y * sv.y; acc0 += a0.z * sv.z; acc0 += a0.w * sv.w;
+                acc1 += a1.x * sv.x; acc1 += a1.y * sv.y; acc1 += a1.z * sv.z; acc1 += a1.w * sv.w;
+                acc2 += a2.x * sv.x; acc2 += a2.y * sv.y; acc2 += a2.z * sv.z; acc2 += a2.w * sv.w;
+                acc3 += a3.x * sv.x; acc3 += a3.y * sv.y; acc3 += a3.z * sv.z; acc3 += a3.w * sv.w;
+            }
+            if (lane < nb) {
+                float* o = a.tbias + (size_t)(b0 + lane) * a.width + r;
+                o[0] = acc0 + a.b[r];
+                o[1] = acc1 + a.b[r + 1];
+                o[2] = acc2 + a.b[r + 2];
+                o[3] = acc3 + a.b[r + 3];
+            }
         }
+        __syncthreads();
     }
 }
 
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_time_mlp, dim3(a.B, 8), dim3(256), 0, stream, a);
+    if (a.width % TM_ROWS || a.enc_width % TM_ROWS || a.dim % 8) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.dim / 4) * TM_GROUP * sizeof(float4);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_time_mlp),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_time_mlp, dim3(a.width / TM_ROWS), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -405,7 +446,9 @@ __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, u
     r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
+// Contraction off here too: every kernel that draws noise must round the draws identically.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+#pragma clang fp contract(off)
     const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
     const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
     const float rad = sqrtf(-2.0f * logf(u1));
@@ -461,12 +504,63 @@ hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, fl
     return hipGetLastError();
 }
 
-__global__ void k_fill_i64(int64_t* p, int64_t v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+// The same update driven by the device-resident sampler state (see SampleState): coefficients come from
+// a per-timestep table, the timestep-1 update adds no noise, and block 0 hands the next timestep to the
+// next UNet evaluation.
+__global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x, const float* __restrict__ eps,
+                                                           const float4* __restrict__ coef, SampleState* state,
+                                                           size_t n4) {
+    const int t = state->t_upd;
+    const float4 c = coef[t];
+    const bool noisy = t > 1;
+    const bool philox = noisy && state->philox;
+    const unsigned long long seed = state->seed;
+    const float* noise = (noisy && !state->philox && state->noise) ? state->noise + (size_t)(state->t_max - t) * (n4 * 4)
+                                                                  : nullptr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 xv = reinterpret_cast<float4*>(x)[i];
+        const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (philox) {
+            uint32_t r[4];
+            philox4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)t, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            box_muller(r[0], r[1], z.x, z.y);
+            box_muller(r[2], r[3], z.z, z.w);
+        } else if (noise) {
+            z = reinterpret_cast<const float4*>(noise)[i];
+        }
+        xv.x = ddpm_one(xv.x, ev.x, z.x, c.x, c.y, c.z);
+        xv.y = ddpm_one(xv.y, ev.y, z.y, c.x, c.y, c.z);
+        xv.z = ddpm_one(xv.z, ev.z, z.z, c.x, c.y, c.z);
+        xv.w = ddpm_one(xv.w, ev.w, z.w, c.x, c.y, c.z);
+        reinterpret_cast<float4*>(x)[i] = xv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) state->t_fwd = t - 1;
 }
-hipError_t launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(k_fill_i64, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+
+hipError_t launch_ddpm_update_state(float* x, const float* eps, const float4* coef, SampleState* state, size_t n,
+                                    hipStream_t stream) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_ddpm_update_state, dim3(blocks), dim3(256), 0, stream, x, eps, coef, state, n4);
+    return hipGetLastError();
+}
+
+__global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise) {
+    if (threadIdx.x == 0) {
+        s->t_fwd = t_start;
+        s->t_upd = t_start;
+        s->t_max = t_start;
+        s->philox = philox;
+        s->seed = seed;
+        s->noise = noise;
+    }
+}
+hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, stream, s, t_start, philox, seed, noise);
     return hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ _SIGNATURES = {
                                                 ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_sample": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_int, _P, _P]),
+    "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                          ctypes.POINTER(ctypes.c_double)]),
@@ -180,6 +181,11 @@ class UNetEngine:
             _check(self.lib, self.lib.danra_pack_weights(self.handle, _stream()), "danra_pack_weights")
             torch.cuda.current_stream().synchronize()  # `keep` may be freed after this
         del keep
+
+    def set_graph_mode(self, enable):
+        """True (default): sample() replays one captured hipGraph per denoise step; False: every kernel of
+        every step is enqueued.  Same kernels, bit-identical results."""
+        _check(self.lib, self.lib.danra_set_graph_mode(self.handle, int(bool(enable))), "danra_set_graph_mode")
 
     # ------------------------------------------------------------------ measurement
     def profile_begin(self, kind=1):

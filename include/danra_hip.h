@@ -104,12 +104,22 @@ int danra_ddpm_update_philox(float* x_dev, const float* eps_dev, float c1, float
  * i = T-1 ... 1 on the device, x updated in place.  betas/alphas/alpha_hat are HOST fp32 arrays of
  * length T (DiffusionUtils.betas/.alphas/.alpha_hat, diffusion:47-51).  trace_dev (may be NULL)
  * receives x after the update of each timestep listed in trace_steps (host int array, n_trace
- * entries, [n_trace,B,1,H,W] floats).  Asynchronous on `stream`. */
+ * entries, [n_trace,B,1,H,W] floats).  Asynchronous on `stream`.
+ * The loop state (timestep, coefficients, noise cursor) lives on the device, so one denoise step needs
+ * no host argument: by default the step (every kernel of one UNet evaluation + the update) is captured
+ * once per (B, H, W) into a hipGraph and replayed T-1 times; inputs are copied into the handle's
+ * workspace first, so the captured step never refers to caller memory. */
 int danra_sample(danra_handle_t h, float* x_dev, const int64_t* y_dev, const float* cond_dev,
                  const float* lsm_dev, const float* topo_dev, int B, int H, int W, int T,
                  const float* betas, const float* alphas, const float* alpha_hat, int noise_mode,
                  const float* noise_dev, uint64_t seed, const int* trace_steps, int n_trace,
                  float* trace_dev, void* stream);
+
+/* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
+ * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns
+ * it off), 0 enqueues every kernel of every step.  Both modes run the same kernels on the same data and
+ * give bit-identical results.  While a danra_profile_begin measurement is active the loop is enqueued. */
+int danra_set_graph_mode(danra_handle_t h, int enable);
 
 /* Measurement hook (no counterpart in the reference, which holds no timing code): between _begin and
  * _end every launch of the named kernel family is bracketed by HIP events on the stream it is launched

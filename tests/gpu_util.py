@@ -101,3 +101,11 @@ class Ops:
                                                     ctypes.c_float(c2), ctypes.c_float(c3), x.numel(), _stream()),
                "danra_ddpm_update")
         return x
+
+    def ddpm_update_philox(self, x, eps, c1, c2, c3, seed, step):
+        x = x.clone()
+        _check(self.lib, self.lib.danra_ddpm_update_philox(_ptr(x), _ptr(eps), ctypes.c_float(c1), ctypes.c_float(c2),
+                                                           ctypes.c_float(c3), x.numel(), ctypes.c_uint64(seed),
+                                                           ctypes.c_uint64(step), _stream()),
+               "danra_ddpm_update_philox")
+        return x

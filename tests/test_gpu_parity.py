@@ -291,3 +291,59 @@ def test_full_size_batch_properties(cond64, dev):
     du.noise_seed = 1235
     c = du.sample(inp["x"], model, inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"])
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+def test_graph_replay_equals_enqueued_loop(cond64, dev):
+    """The captured-step replay and the kernel-by-kernel loop are the same computation: bit-identical in both
+    noise modes, with the trace taken between replays, and across a change of batch size (new capture)."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, _ = cond64
+    engine = model.hip_engine(dev)
+    T = 12
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    try:
+        for B in (3, 2):
+            inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64, seed=21).items()}
+            noise = gs.randn(77, T - 2, B, 1, 64, 64).to(dev)
+            res = {}
+            for graph in (True, False):
+                engine.set_graph_mode(graph)
+                xh, tr = engine.sample(inp["x"].clone(), inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"],
+                                       du.betas, du.alphas, du.alpha_hat, noise=noise, trace_steps=[T - 1, 5, 1])
+                xp = engine.sample(inp["x"].clone(), inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"],
+                                   du.betas, du.alphas, du.alpha_hat, seed=99)
+                res[graph] = (xh, tr, xp)
+            for a, b in zip(res[True], res[False]):
+                assert torch.equal(a, b)
+            assert torch.equal(res[True][1][2], res[True][0])  # the trace entry of timestep 1 is the final x
+    finally:
+        engine.set_graph_mode(True)
+
+
+def test_sampler_loop_equals_its_parts(cond64, dev):
+    """danra_sample == forward + update composed by hand through the per-call entry points (Philox stream
+    keyed by the timestep, fp32 coefficients as the reference computes them)."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, _ = cond64
+    engine = model.hip_engine(dev)
+    ops = cond64[2]
+    T, B, seed = 5, 2, 4242
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64, seed=5).items()}
+    got = engine.sample(inp["x"].clone(), inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"], du.betas,
+                        du.alphas, du.alpha_hat, seed=seed)
+    # IEEE fp32 scalar arithmetic (numpy), the way the library's host loop evaluates diffusion:135-157
+    betas, alphas, alpha_hat = (v.cpu().numpy() for v in (du.betas, du.alphas, du.alpha_hat))
+    one = np.float32(1)
+    x = inp["x"].clone()
+    for i in range(T - 1, 0, -1):
+        t = torch.full((B,), i, device=dev, dtype=torch.long)
+        eps = engine.forward(x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        c1 = one / np.sqrt(alphas[i])
+        c2 = (one - alphas[i]) / np.sqrt(one - alpha_hat[i])
+        c3 = np.sqrt(betas[i])
+        if i > 1:
+            x = ops.ddpm_update_philox(x, eps, float(c1), float(c2), float(c3), seed, i)
+        else:
+            x = ops.ddpm_update(x, eps, None, float(c1), float(c2), float(c3))
+    assert torch.equal(got, x)
