@@ -555,6 +555,7 @@ int run_time_mlp(danra_handle_s* h, const int64_t* t, SampleState* state, const 
     a.enc_inv_freq = h->enc_inv_freq; a.dec_div = h->dec_div; a.W = h->tw; a.b = h->tb;
     a.enc_emb_out = enc_out; a.dec_emb_out = dec_out; a.tbias = tbias;
     a.B = B; a.dim = h->cfg.time_embedding; a.width = h->tb_width; a.enc_width = h->enc_width;
+    a.num_classes = h->cfg.num_classes;
     HIP_TRY(launch_time_mlp(a, st));
     return DANRA_OK;
 }

@@ -79,7 +79,7 @@ struct TimeMlpArgs {
     float* enc_emb_out;        // [B][dim] or null
     float* dec_emb_out;        // [B][dim] or null
     float* tbias;              // [B][width] or null
-    int B, dim, width, enc_width;
+    int B, dim, width, enc_width, num_classes;
 };
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
 

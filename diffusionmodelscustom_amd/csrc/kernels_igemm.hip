@@ -389,8 +389,161 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-stationary GEMM for K == 64 (the 64-channel attention projections and transposed convolutions:
+// M is tens of thousands of tokens, N = 64..256, so there is no K loop to pipeline and the work is
+// bound by moving A and the output).  The whole weight matrix sits in LDS ([N][68] floats, loaded once
+// per workgroup, every load in flight before the first LDS write); after that single barrier every
+// wave works alone on its own 32 rows: it loads them straight into MFMA fragment registers (lane
+// (i, h) holds k = 8u+4h..8u+4h+3 of row i, the same convention as k_igemm), applies the LayerNorm in
+// registers (a row's 64 values live in lanes i and i+32), then walks N in 32-column steps of 32 MFMAs +
+// epilogue.  The product is formed transposed (weights as the MFMA A operand), so a lane ends up with
+// runs of four consecutive output columns of ONE output row: 16-byte stores, 4x fewer store
+// instructions than the row-major accumulator layout, and the lane's own row offset serves them all.
+// With no barrier in the walk the waves of a CU drift apart, so loads, matrix work and stores of
+// different waves overlap.
+template <int NW4>  // weight float4 loads a thread keeps in flight
+__global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
+    constexpr int LDK = 68;
+    extern __shared__ __attribute__((aligned(16))) float Wsm[];  // [N][LDK] then the column-offset table
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int waves = blockDim.x >> 6;
+    const int fr = lane & 31;
+    const int fh = (lane >> 5) * 4;
+    // wave task = (32-row tile, 1/nsplit of the columns); the tasks of one tile sit in adjacent waves
+    const int nsplit = p.force_kw > 0 ? p.force_kw : 1;
+    const int task = blockIdx.x * waves + wave;
+    const int m0 = (task / nsplit) * 32;
+    const int nt_per = p.N / 32 / nsplit;
+    const int nt_begin = (task % nsplit) * nt_per;
+    unsigned long long* coloff = reinterpret_cast<unsigned long long*>(Wsm + (size_t)p.N * LDK);  // [N/4]
+    float* bias_s = reinterpret_cast<float*>(coloff + p.N / 4);                                  // [N]
+
+    // ---- this wave's 32 rows, in fragment order (clamped rows are computed and never stored)
+    const int mrow = m0 + fr;
+    const int arow = min(mrow, p.M - 1);
+    float4 a[8];
+    {
+        const float* src = p.A + (size_t)arow * p.lda + fh;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) a[kb] = *reinterpret_cast<const float4*>(src + kb * 8);
+    }
+    // the residual of the wave's output (only offered for N == 64): loaded now, so that the walk below
+    // issues no global load at all and its stores never have to be waited for
+    float4 resv[8];
+    if (p.res) {
+        const float* rs = p.res + (size_t)arow * p.ldr + fh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) resv[j] = *reinterpret_cast<const float4*>(rs + (j >> 2) * 32 + (j & 3) * 8);
+    }
+    // ---- the weights: N rows of 64 floats -> LDS
+    const int total = p.N * 16;
+    for (int q0 = tid; q0 < total; q0 += NW4 * (int)blockDim.x) {
+        float4 w[NW4];
+#pragma unroll
+        for (int j = 0; j < NW4; ++j) {
+            const int q = min(q0 + j * (int)blockDim.x, total - 1);
+            w[j] = *reinterpret_cast<const float4*>(p.W + (size_t)q * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NW4; ++j) {
+            const int q = q0 + j * (int)blockDim.x;
+            if (q < total) *reinterpret_cast<float4*>(Wsm + (q >> 4) * LDK + (q & 15) * 4) = w[j];
+        }
+    }
+    for (int g = tid; g < p.N / 4; g += blockDim.x) coloff[g] = col_offset(p, g * 4);
+    for (int n = tid; n < p.N; n += blockDim.x) bias_s[n] = p.bias ? p.bias[n] : 0.f;
+    int img;
+    const unsigned long long my_off = row_offset(p, arow, img);
+    if (p.ln) {  // two-pass LayerNorm statistics; lanes i and i+32 hold the two halves of row i
+        float s = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) s += (a[kb].x + a[kb].y) + (a[kb].z + a[kb].w);
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 64.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const float dx = a[kb].x - mean, dy = a[kb].y - mean, dz = a[kb].z - mean, dw = a[kb].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q += __shfl_xor(q, 32);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            a[kb].x = (a[kb].x - mean) * rstd;
+            a[kb].y = (a[kb].y - mean) * rstd;
+            a[kb].z = (a[kb].z - mean) * rstd;
+            a[kb].w = (a[kb].w - mean) * rstd;
+        }
+    }
+    __syncthreads();
+    if (m0 >= p.M) return;
+    float* outrow = p.out + my_off;
+
+    for (int nt = nt_begin; nt < nt_begin + nt_per; ++nt) {
+        // acc[r] = out[row m0 + (lane & 31)][column nt*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* Bs = Wsm + (nt * 32 + fr) * LDK + fh;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[kb].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[kb].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[kb].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + fh;
+            float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            const float4 bv = *reinterpret_cast<const float4*>(bias_s + n);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.res) {  // N == 64 here: nt in {0, 1}
+                const float4 rv = resv[(nt & 1) * 4 + g];
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (mrow < p.M) *reinterpret_cast<float4*>(outrow + coloff[n >> 2]) = v;
+        }
+    }
+}
+
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    // every store mode keeps runs of four output columns contiguous when its inner extent is a multiple of 4
+    const bool vec4 = a.ldc % 4 == 0 && (a.st_mode != ST_QKV || a.qkv_hd % 4 == 0) && (a.st_mode != ST_CONVT || a.ct_C % 4 == 0) &&
+                      (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
+    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && vec4 && !a.tbias &&
+        (!a.res || a.N == 64)) {
+        // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
+        const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
+        const int tiles = (a.M + 31) / 32 * nsplit;
+        int waves = 1;  // as many waves share one copy of the weights as keeps every CU busy
+        while (waves < 16 && tiles > 256 * waves) waves *= 2;
+        IGemmArgs b = a;
+        b.force_kw = nsplit;  // reused as the column split of a wave task
+        const size_t lds = (size_t)a.N * 68 * sizeof(float) + (size_t)(a.N / 4) * sizeof(unsigned long long) + (size_t)a.N * sizeof(float);
+        const int nw4 = (a.N * 16 + 64 * waves - 1) / (64 * waves);
+        const dim3 grid((tiles + waves - 1) / waves), block(64 * waves);
+#define DANRA_LAUNCH_K64(NW4_)                                                                              \
+    do {                                                                                                    \
+        if (lds > 48 * 1024) {                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_k64<NW4_>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            if (e != hipSuccess) return e;                                                                  \
+        }                                                                                                   \
+        hipLaunchKernelGGL(k_gemm_k64<NW4_>, grid, block, lds, stream, b);                                  \
+    } while (0)
+        if (nw4 <= 4) DANRA_LAUNCH_K64(4);
+        else DANRA_LAUNCH_K64(16);
+#undef DANRA_LAUNCH_K64
+        return hipGetLastError();
+    }
     int bm = a.force_bm, kw = a.force_kw;
     if (!bm) {
         // Enough wave-level parallelism for 256 CUs x 4 SIMDs is the first concern; operand reuse second.

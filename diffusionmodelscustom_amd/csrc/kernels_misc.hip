@@ -16,74 +16,118 @@ namespace danra {
 // through wave-uniform (scalar) loads.  The sin/cos of a timestep is evaluated once per run of equal
 // timesteps (the sampler gives every image the same one).
 constexpr int TM_ROWS = 16;
-constexpr int TM_GROUP = 65;  // float4 per k-group row
+constexpr int TM_GROUP = 65;    // float4 per k-group row
+constexpr int TM_MAX_CLS = 16;  // label classes served by the per-class table
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
-    extern __shared__ float4 tm_s[];  // [dim/4][TM_GROUP]
+    extern __shared__ float4 tm_s[];  // [dim/4][TM_GROUP] SiLU(emb) | [TM_ROWS][dim] weights | [TM_MAX_CLS][dim] per-class
+    __shared__ int s_y[64];
+    __shared__ int s_uniform;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = a.dim / 2;
     const int row0 = blockIdx.x * TM_ROWS;
     const bool enc_rows = row0 < a.enc_width;
-    const bool write_emb = blockIdx.x == 0;
-    const bool dec_needed = !enc_rows || (write_emb && a.dec_emb_out);
-    const bool enc_needed = enc_rows || (write_emb && a.enc_emb_out);
+    const bool write_emb = blockIdx.x == 0 && (a.enc_emb_out || a.dec_emb_out);
+    const bool dec_needed = !enc_rows || write_emb;
+    const bool enc_needed = enc_rows || write_emb;
+    float* s_flat = reinterpret_cast<float*>(tm_s);
+    float* s_w = s_flat + (size_t)(a.dim / 4) * TM_GROUP * 4;
+    float* s_cls = s_w + (size_t)TM_ROWS * a.dim;
     int t_state = 0;
     if (a.state) {
         t_state = a.state->t_fwd;
         if (blockIdx.x == 0 && tid == 0) a.state->t_upd = t_state;
     }
-    float* s_flat = reinterpret_cast<float*>(tm_s);
+    // this block's weight rows: coalesced into LDS once
+    for (int q = tid; q < TM_ROWS * a.dim / 4; q += 256)
+        reinterpret_cast<float4*>(s_w)[q] = reinterpret_cast<const float4*>(a.W + (size_t)row0 * a.dim)[q];
+    const bool labels = enc_needed && a.y;
     for (int b0 = 0; b0 < a.B; b0 += 64) {
         const int nb = min(64, a.B - b0);
-        for (int j = tid; j < a.dim; j += 256) {
-            const int k = j < half ? j : j - half;
-            const float f_enc = a.enc_inv_freq[k];
-            const float f_dec = a.dec_div[j >> 1];
-            long long t_prev = -1;
-            float e_base = 0.f, d_base = 0.f;
-            for (int bb = 0; bb < nb; ++bb) {
-                const int b = b0 + bb;
-                const long long ti = a.state ? (long long)t_state : a.t[b];
-                if (bb == 0 || ti != t_prev) {
-                    const float tf = (float)ti;
-                    if (enc_needed) {
-                        // encoder: [sin(t*f_0..f_half-1) | cos(...)], base 1000
-                        const float arg = tf * f_enc;
-                        e_base = j < half ? sinf(arg) : cosf(arg);
-                    }
-                    if (dec_needed) {
-                        // decoder: interleaved sin/cos of t / 10000^(2k/dim)
-                        const float argd = tf / f_dec;
-                        d_base = (j & 1) ? cosf(argd) : sinf(argd);
-                    }
-                    t_prev = ti;
+        if (tid == 0) s_uniform = 1;
+        __syncthreads();
+        if (tid < nb) {
+            const int yb = labels ? (int)a.y[b0 + tid] : 0;
+            s_y[tid] = yb;
+            const bool same_t = a.state || a.t[b0 + tid] == a.t[b0];
+            if (!same_t || (labels && (yb < 0 || yb >= TM_MAX_CLS))) s_uniform = 0;
+        }
+        __syncthreads();
+        const bool uniform = s_uniform && !write_emb;
+        if (uniform) {
+            // one timestep for the whole chunk: evaluate per label class, then scatter by label
+            const long long ti = a.state ? (long long)t_state : a.t[b0];
+            const float tf = (float)ti;
+            const int ncls = labels ? min(a.num_classes, TM_MAX_CLS) : 1;
+            for (int j = tid; j < a.dim; j += 256) {
+                float base;
+                if (enc_rows) {
+                    const float arg = tf * a.enc_inv_freq[j < half ? j : j - half];
+                    base = j < half ? sinf(arg) : cosf(arg);
+                } else {
+                    const float argd = tf / a.dec_div[j >> 1];
+                    base = (j & 1) ? cosf(argd) : sinf(argd);
                 }
-                float e = e_base;
-                if (enc_needed && a.y) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
-                if (write_emb) {
-                    if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
-                    if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d_base;
+                for (int c = 0; c < ncls; ++c) {
+                    const float v = labels ? base + a.label_emb[(size_t)c * a.dim + j] : base;
+                    s_cls[c * a.dim + j] = silu(v);
                 }
-                const float v = enc_rows ? e : d_base;
-                s_flat[((j >> 2) * TM_GROUP + bb) * 4 + (j & 3)] = v / (1.0f + expf(-v));  // SiLU
+            }
+            __syncthreads();
+            // lane = image: copy its class row, one float4 group per step
+            const int yb = labels ? s_y[lane] : 0;
+            const float4* src = reinterpret_cast<const float4*>(s_cls) + (size_t)yb * (a.dim / 4);
+            for (int g = tid >> 6; g < a.dim / 4; g += 4) tm_s[g * TM_GROUP + lane] = src[g];
+        } else {
+            for (int j = tid; j < a.dim; j += 256) {
+                const float f_enc = a.enc_inv_freq[j < half ? j : j - half];
+                const float f_dec = a.dec_div[j >> 1];
+                long long t_prev = -1;
+                float e_base = 0.f, d_base = 0.f;
+                for (int bb = 0; bb < nb; ++bb) {
+                    const int b = b0 + bb;
+                    const long long ti = a.state ? (long long)t_state : a.t[b];
+                    if (bb == 0 || ti != t_prev) {
+                        const float tf = (float)ti;
+                        if (enc_needed) {
+                            // encoder: [sin(t*f_0..f_half-1) | cos(...)], base 1000
+                            const float arg = tf * f_enc;
+                            e_base = j < half ? sinf(arg) : cosf(arg);
+                        }
+                        if (dec_needed) {
+                            // decoder: interleaved sin/cos of t / 10000^(2k/dim)
+                            const float argd = tf / f_dec;
+                            d_base = (j & 1) ? cosf(argd) : sinf(argd);
+                        }
+                        t_prev = ti;
+                    }
+                    float e = e_base;
+                    if (labels) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
+                    if (write_emb) {
+                        if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
+                        if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d_base;
+                    }
+                    s_flat[((j >> 2) * TM_GROUP + bb) * 4 + (j & 3)] = silu(enc_rows ? e : d_base);
+                }
             }
         }
         __syncthreads();
         if (a.tbias) {
             const int r = row0 + wave * 4;
-            const float* w0 = a.W + (size_t)r * a.dim;
-            const float* w1 = w0 + a.dim;
-            const float* w2 = w1 + a.dim;
-            const float* w3 = w2 + a.dim;
+            const float4* w0 = reinterpret_cast<const float4*>(s_w + (size_t)(wave * 4) * a.dim);
+            const int ld4 = a.dim / 4;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            for (int k4 = 0; k4 < a.dim / 4; ++k4) {
+#pragma unroll 4
+            for (int k4 = 0; k4 < ld4; ++k4) {
                 const float4 sv = tm_s[k4 * TM_GROUP + lane];
-                const float4 a0 = *reinterpret_cast<const float4*>(w0 + 4 * k4);
-                const float4 a1 = *reinterpret_cast<const float4*>(w1 + 4 * k4);
-                const float4 a2 = *reinterpret_cast<const float4*>(w2 + 4 * k4);
-                const float4 a3 = *reinterpret_cast<const float4*>(w3 + 4 * k4);
+                const float4 a0 = w0[k4];
+                const float4 a1 = w0[ld4 + k4];
+                const float4 a2 = w0[2 * ld4 + k4];
+                const float4 a3 = w0[3 * ld4 + k4];
                 acc0 += a0.x * sv.x; acc0 += a0.y * sv.y; acc0 += a0.z * sv.z; acc0 += a0.w * sv.w;
                 acc1 += a1.x * sv.x; acc1 += a1.y * sv.y; acc1 += a1.z * sv.z; acc1 += a1.w * sv.w;
                 acc2 += a2.x * sv.x; acc2 += a2.y * sv.y; acc2 += a2.z * sv.z; acc2 += a2.w * sv.w;
@@ -103,7 +147,7 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
 
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
     if (a.width % TM_ROWS || a.enc_width % TM_ROWS || a.dim % 8) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(a.dim / 4) * TM_GROUP * sizeof(float4);
+    const size_t lds = ((size_t)(a.dim / 4) * TM_GROUP * 4 + (size_t)(TM_ROWS + TM_MAX_CLS) * a.dim) * sizeof(float);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_time_mlp),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
         {"qkv L4 C512 (ln)", A_GEMM, B, 2, 2, 512, 1536, 1, 1, 0, 1, ST_QKV},
     };
     struct Cfg { int bm, kw, ks; };
-    std::vector<Cfg> cfgs = {{128, 1, 1}, {64, 1, 1}, {64, 2, 1}, {64, 4, 1}, {64, 4, 2}, {64, 4, 4}, {64, 4, 8},
+    std::vector<Cfg> cfgs = {{0, 0, 1}, {128, 1, 1}, {64, 1, 1}, {64, 2, 1}, {64, 4, 1}, {64, 4, 2}, {64, 4, 4}, {64, 4, 8},
                              {64, 2, 2}, {64, 2, 4}, {64, 1, 4}, {128, 1, 2}, {128, 1, 4}};
     const size_t big = (size_t)B * 64 * 64 * 64 + (1 << 20);
     float *A, *W, *out, *res, *bias, *partial;
