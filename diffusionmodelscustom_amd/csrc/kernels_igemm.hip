@@ -277,10 +277,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                    // weights as the MFMA A operand: the product comes out transposed, so that a lane
+                    // owns runs of four consecutive output columns of one output row (16-byte epilogue)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].x, a.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].y, a.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].z, a.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].w, a.w, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -336,32 +338,37 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 for (int r = 0; r < 16; ++r) acc[t][r] += red[((((kp - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane];
     }
 
-    // ---- epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-    int ncol[NT];
-    float nbias[NT];
-    unsigned long long ncoff[NT];
+    // ---- epilogue.  acc[t][r] = out[row m0 + row0 + (lane & 31)][column n0 + col0 + 32t + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
+    const int row = row0 + fr;
+    const int m = m0 + row;
+    if (m >= p.M) return;
+    const unsigned long long ro = rowOff[row];
+    const int img = rowImg[row];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        ncol[t] = n0 + col0 + t * 32 + fr;
-        nbias[t] = p.bias ? p.bias[ncol[t]] : 0.f;
-        ncoff[t] = col_offset(p, ncol[t]);
-    }
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + fh;
-        const int m = m0 + row;
-        if (m < p.M) {
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + col0 + t * 32 + 8 * g + fh;
+            float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
             if (p.ksplit > 1) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) p.partial[((size_t)blockIdx.z * p.M + m) * p.N + ncol[t]] = acc[t][r];
-            } else {
-                const unsigned long long ro = rowOff[row];
-                const int img = rowImg[row];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) p.out[ro + ncoff[t]] = finish(p, acc[t][r], nbias[t], m, ncol[t], img);
+                *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = v;
+                continue;
             }
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (p.res) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + n);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.tbias) {
+                const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)img * p.tb_stride + n);
+                v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
+            }
+            *reinterpret_cast<float4*>(p.out + ro + col_offset(p, n)) = v;
         }
-    }
 }
 
 // Sums the split-K slabs in slab order (bitwise reproducible) and applies the epilogue.
@@ -518,7 +525,8 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     // every store mode keeps runs of four output columns contiguous when its inner extent is a multiple of 4
     const bool vec4 = a.ldc % 4 == 0 && (a.st_mode != ST_QKV || a.qkv_hd % 4 == 0) && (a.st_mode != ST_CONVT || a.ct_C % 4 == 0) &&
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
-    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && vec4 && !a.tbias &&
+    if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
+    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && !a.tbias &&
         (!a.res || a.N == 64)) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
