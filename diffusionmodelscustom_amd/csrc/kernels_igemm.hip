@@ -338,37 +338,46 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 for (int r = 0; r < 16; ++r) acc[t][r] += red[((((kp - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane];
     }
 
-    // ---- epilogue.  acc[t][r] = out[row m0 + row0 + (lane & 31)][column n0 + col0 + 32t + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
-    const int row = row0 + fr;
-    const int m = m0 + row;
-    if (m >= p.M) return;
-    const unsigned long long ro = rowOff[row];
-    const int img = rowImg[row];
+    // ---- epilogue.  acc[t][r] = out[row m0 + row0 + (lane & 31)][column n0 + col0 + 32t + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)].
+    // The tile goes through LDS once so that 16 consecutive lanes own one whole 64-column output row: residual
+    // loads and stores are then 256-byte contiguous per row, and a thread needs one column offset for all its rows.
+    constexpr int LDO = BN + 4;
+    float* tile = smem;
+    __syncthreads();  // (the waves still alive) every read of the staging / reduction buffers has retired
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + col0 + t * 32 + 8 * g + fh;
-            float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-            if (p.ksplit > 1) {
-                *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = v;
-                continue;
-            }
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            }
-            if (p.res) {
-                const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + n);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.tbias) {
-                const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)img * p.tb_stride + n);
-                v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
-            }
-            *reinterpret_cast<float4*>(p.out + ro + col_offset(p, n)) = v;
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(tile + (row0 + fr) * LDO + col0 + t * 32 + 8 * g + fh) =
+                make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    __syncthreads();
+    const int oc4 = (tid & 15) * 4;
+    const int n = n0 + oc4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && p.ksplit <= 1) bv = *reinterpret_cast<const float4*>(p.bias + n);
+    const unsigned long long co = col_offset(p, n);
+#pragma unroll
+    for (int j = 0; j < BM / 16; ++j) {
+        const int row = (tid >> 4) + 16 * j;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(tile + row * LDO + oc4);
+        if (p.ksplit > 1) {
+            *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = v;
+            continue;
         }
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.res) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + n);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.tbias) {
+            const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)rowImg[row] * p.tb_stride + n);
+            v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
+        }
+        *reinterpret_cast<float4*>(p.out + rowOff[row] + co) = v;
+    }
 }
 
 // Sums the split-K slabs in slab order (bitwise reproducible) and applies the epilogue.
@@ -526,7 +535,8 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const bool vec4 = a.ldc % 4 == 0 && (a.st_mode != ST_QKV || a.qkv_hd % 4 == 0) && (a.st_mode != ST_CONVT || a.ct_C % 4 == 0) &&
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
     if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
-    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && !a.tbias &&
+    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
+        a.M >= 32768 && !a.tbias &&
         (!a.res || a.N == 64)) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
