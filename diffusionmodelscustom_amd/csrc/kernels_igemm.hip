@@ -436,6 +436,8 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
     const int nt_begin = (task % nsplit) * nt_per;
     unsigned long long* coloff = reinterpret_cast<unsigned long long*>(Wsm + (size_t)p.N * LDK);  // [N/4]
     float* bias_s = reinterpret_cast<float*>(coloff + p.N / 4);                                  // [N]
+    constexpr int LDO = 36;
+    float* stage = bias_s + p.N + wave * 32 * LDO;  // this wave's 32x32 output staging tile
 
     // ---- this wave's 32 rows, in fragment order (clamped rows are computed and never stored)
     const int mrow = m0 + fr;
@@ -445,14 +447,6 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
         const float* src = p.A + (size_t)arow * p.lda + fh;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) a[kb] = *reinterpret_cast<const float4*>(src + kb * 8);
-    }
-    // the residual of the wave's output (only offered for N == 64): loaded now, so that the walk below
-    // issues no global load at all and its stores never have to be waited for
-    float4 resv[8];
-    if (p.res) {
-        const float* rs = p.res + (size_t)arow * p.ldr + fh;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) resv[j] = *reinterpret_cast<const float4*>(rs + (j >> 2) * 32 + (j & 3) * 8);
     }
     // ---- the weights: N rows of 64 floats -> LDS
     const int total = p.N * 16;
@@ -495,9 +489,19 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
             a[kb].w = (a[kb].w - mean) * rstd;
         }
     }
+    // the walk stores through a wave-private LDS tile so that 8 consecutive lanes own 32 consecutive columns
+    // of one row (128-byte runs); lane l then serves rows (l >> 3) + 8j
+    const int orow = lane >> 3;
+    const int oc4 = (lane & 7) * 4;
+    unsigned long long roff4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned lo = __shfl((unsigned)my_off, orow + 8 * j);
+        const unsigned hi = __shfl((unsigned)(my_off >> 32), orow + 8 * j);
+        roff4[j] = ((unsigned long long)hi << 32) | lo;
+    }
     __syncthreads();
     if (m0 >= p.M) return;
-    float* outrow = p.out + my_off;
 
     for (int nt = nt_begin; nt < nt_begin + nt_per; ++nt) {
         // acc[r] = out[row m0 + (lane & 31)][column nt*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
@@ -514,17 +518,18 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = nt * 32 + 8 * g + fh;
-            float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-            const float4 bv = *reinterpret_cast<const float4*>(bias_s + n);
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(stage + fr * LDO + 8 * g + fh) =
+                make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        const int n = nt * 32 + oc4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias_s + n);
+        const unsigned long long co = coloff[n >> 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (p.res) {  // N == 64 here: nt in {0, 1}
-                const float4 rv = resv[(nt & 1) * 4 + g];
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (mrow < p.M) *reinterpret_cast<float4*>(outrow + coloff[n >> 2]) = v;
+            if (m0 + orow + 8 * j < p.M) *reinterpret_cast<float4*>(p.out + roff4[j] + co) = v;
         }
     }
 }
@@ -536,16 +541,16 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
     if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
     if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
-        a.M >= 32768 && !a.tbias &&
-        (!a.res || a.N == 64)) {
+        a.M >= 32768 && !a.tbias && !a.res) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
         const int tiles = (a.M + 31) / 32 * nsplit;
-        int waves = 1;  // as many waves share one copy of the weights as keeps every CU busy
-        while (waves < 16 && tiles > 256 * waves) waves *= 2;
         IGemmArgs b = a;
         b.force_kw = nsplit;  // reused as the column split of a wave task
-        const size_t lds = (size_t)a.N * 68 * sizeof(float) + (size_t)(a.N / 4) * sizeof(unsigned long long) + (size_t)a.N * sizeof(float);
+        int waves = 1;  // as many waves share one copy of the weights as keeps every CU busy
+        while (waves < 16 && tiles > 256 * waves) waves *= 2;
+        const size_t lds = (size_t)a.N * 68 * sizeof(float) + (size_t)(a.N / 4) * sizeof(unsigned long long) +
+                           (size_t)a.N * sizeof(float) + (size_t)waves * 32 * 36 * sizeof(float);
         const int nw4 = (a.N * 16 + 64 * waves - 1) / (64 * waves);
         const dim3 grid((tiles + waves - 1) / waves), block(64 * waves);
 #define DANRA_LAUNCH_K64(NW4_)                                                                              \
