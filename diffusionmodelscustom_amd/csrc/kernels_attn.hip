@@ -6,13 +6,16 @@
 // are lane-local plus two cross-lane exchanges; the same accumulator registers are then the B
 // operand of O^T = V^T P^T without passing through LDS.  Online softmax in the exp2 domain.
 //
-// k_attn_small: every other shape of the network (L <= 256, head_dim 32..128); one wave per query
-// row, K/V of the (image, head) pair resident in LDS.  These shapes hold < 1 % of the FLOPs.
+// k_attn_reg: the deeper levels (L <= 256 tokens, head_dim 32 / 64 / 128): one wave per 16-query tile, all
+// score tiles in registers, exact two-pass softmax, operands read straight from memory.
+//
+// k_attn_small: fallback for any other shape (one wave per query row, K/V of the (image, head) pair in LDS).
 #include "danra_kernels.h"
 
 namespace danra {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 
 // QT = 16-query tiles per wave (template parameter of k_flash_hd16)
 static constexpr int KVT = 64;  // keys per LDS tile
@@ -201,6 +204,118 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     }
 }
 
+// Register-resident attention for short sequences (L <= 256) and head_dim = 16*DT: one wave per
+// (batch, head, 16-query tile), no LDS and no barrier.  Same operand trick as k_flash_hd16: the scores
+// are formed transposed (S^T = K Q^T on v_mfma_f32_16x16x4_f32, keys as rows, queries as columns), so a
+// lane's four accumulator registers of a key tile are exactly the B operand of O^T = V^T P^T.  All NKT
+// score tiles stay in registers, which makes the softmax an exact two-pass one (no running rescale).
+// Lane (c = lane & 15, kg = lane >> 4) holds the contiguous head_dim/4 slice kg of Q row c and of K row c:
+// MFMA step s consumes d = (head_dim/4)*kg + s from both operands, and the 16 x head_dim K tile is read
+// with fully coalesced 16-byte loads straight from memory.  Keys >= L are masked to -inf (their loads are
+// clamped), queries >= L are computed and not stored.
+
+template <int DT, int NKT>
+__global__ __launch_bounds__(256) void k_attn_reg(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ V, float* __restrict__ O, int L,
+                                                  int heads, int n_bh, float scale_log2e) {
+    constexpr int HD = 16 * DT;
+    constexpr int HQ = 4 * DT;  // floats of a row per lane
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 15;
+    const int kg = lane >> 4;
+    const int qtiles = (L + 15) >> 4;
+    const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int bh = task / qtiles;
+    const int qt = task - bh * qtiles;
+    if (bh >= n_bh) return;
+    const float* Qb = Q + (size_t)bh * L * HD;
+    const float* Kb = K + (size_t)bh * L * HD;
+    const float* Vb = V + (size_t)bh * L * HD;
+    const int q0 = qt * 16;
+
+    float q[HQ];
+    {
+        const float* src = Qb + (size_t)min(q0 + c, L - 1) * HD + HQ * kg;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * j);
+            q[4 * j] = v.x * scale_log2e; q[4 * j + 1] = v.y * scale_log2e;
+            q[4 * j + 2] = v.z * scale_log2e; q[4 * j + 3] = v.w * scale_log2e;
+        }
+    }
+    // ---- S^T tiles: st[kt][r] = score(query q0 + c, key 16*kt + 4*kg + r), in the log2 domain
+    f32x4 st[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        float kf[HQ];
+        const float* src = Kb + (size_t)min(kt * 16 + c, L - 1) * HD + HQ * kg;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * j);
+            kf[4 * j] = v.x; kf[4 * j + 1] = v.y; kf[4 * j + 2] = v.z; kf[4 * j + 3] = v.w;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < HQ; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], q[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (kt * 16 + 4 * kg + r >= L) acc[r] = -INFINITY;
+            mx = fmaxf(mx, acc[r]);
+        }
+        st[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+            st[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // ---- O^T tiles: ot[dt][r] = out(query q0 + c, d = 16*dt + 4*kg + r)
+    f32x4 ot[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = Vb + (size_t)min(kt * 16 + 4 * kg + r, L - 1) * HD + c;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * dt], st[kt][r], ot[dt], 0, 0, 0);
+        }
+    if (q0 + c < L) {
+        const float inv = 1.0f / sum;
+        const int b = bh / heads, head = bh - b * heads;
+        float* dst = O + ((size_t)b * L + q0 + c) * (heads * HD) + head * HD + 4 * kg;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<float4*>(dst + 16 * dt) =
+                make_float4(ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv);
+    }
+}
+
+template <int DT>
+static hipError_t launch_attn_reg(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                                  hipStream_t stream) {
+    const int n_bh = B * heads;
+    const int tasks = n_bh * ((L + 15) / 16);
+    const int wpb = tasks > 1024 ? 4 : 1;  // one wave per workgroup spreads few tasks over all CUs
+    const dim3 grid((tasks + wpb - 1) / wpb), block(64 * wpb);
+    const float scale_log2e = (1.0f / sqrtf(16.0f * DT)) * 1.4426950408889634f;
+    if (L <= 16) hipLaunchKernelGGL((k_attn_reg<DT, 1>), grid, block, 0, stream, q, k, v, out, L, heads, n_bh, scale_log2e);
+    else if (L <= 64) hipLaunchKernelGGL((k_attn_reg<DT, 4>), grid, block, 0, stream, q, k, v, out, L, heads, n_bh, scale_log2e);
+    else hipLaunchKernelGGL((k_attn_reg<DT, 16>), grid, block, 0, stream, q, k, v, out, L, heads, n_bh, scale_log2e);
+    return hipGetLastError();
+}
+
 // Generic small-shape attention: grid (B*heads, query blocks); K (padded rows) and V in LDS.
 __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O, int L,
@@ -266,6 +381,11 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
         dim3 grid((L / 128) * B * heads);
         hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, B * heads, scale_log2e);
         return hipGetLastError();
+    }
+    if (L <= 256) {
+        if (hd == 32) return launch_attn_reg<2>(q, k, v, out, B, heads, L, stream);
+        if (hd == 64) return launch_attn_reg<4>(q, k, v, out, B, heads, L, stream);
+        if (hd == 128) return launch_attn_reg<8>(q, k, v, out, B, heads, L, stream);
     }
     const size_t lds = ((size_t)L * (hd + 1) + (size_t)L * hd + 4 * (size_t)L + 4 * (size_t)hd) * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
