@@ -158,63 +158,65 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// InstanceNorm statistics on NHWC: block = (image, 32 channels); 8 channel quads x 32 pixel slots.
-// Two passes (mean, then centred sum of squares) so that the biased variance matches a direct
-// evaluation; the second pass re-reads from L2.
+// InstanceNorm statistics on NHWC: block = (image, 32 channels[, pixel slice]); 8 channel quads x 32 pixel
+// slots, NP pixels per thread.  The block's pixels are read ONCE into registers (every load in flight
+// together); the mean and then the centred sum of squares are formed from the registers, so the biased
+// variance matches a direct two-pass evaluation at the cost of a single pass over memory.
 // With gridDim.z = S > 1 the pixels are cut into S equal slices; each block then writes the mean and the
 // centred sum of squares of its slice to part[b][s][{mean, m2}][C] and k_in_stats_merge combines them
 // (Chan et al.'s pairwise update with equal counts), which keeps the two-pass accuracy.
+__device__ __forceinline__ float4 block_sum_by_quad(float4 v, float4* red, int tid) {
+    // threads with equal (tid & 7) hold the same four channels: 8 per wave, 4 waves
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+    }
+    __syncthreads();  // the previous use of `red` has been read
+    if ((tid & 63) < 8) red[(tid >> 6) * 8 + (tid & 7)] = v;
+    __syncthreads();
+    float4 r = red[tid & 7];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 o = red[w * 8 + (tid & 7)];
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    return r;
+}
+
+template <int NP>
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
                                                   float* __restrict__ rstd, float* __restrict__ part, int HWtotal,
                                                   int C) {
-    __shared__ float4 red[256];
+    __shared__ float4 red[32];
     const int b = blockIdx.x;
     const int c0 = blockIdx.y * 32;
     const int tid = threadIdx.x;
     const int cq = (tid & 7) * 4;
     const int slot = tid >> 3;
     const int S = gridDim.z;
-    const int HW = HWtotal / S;
+    const int HW = HWtotal / S;  // <= 32 * NP
     const float* base = x + ((size_t)b * HWtotal + (size_t)blockIdx.z * HW) * C + c0 + cq;
+    float4 v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(base + (size_t)min(slot + 32 * i, HW - 1) * C);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = slot; p < HW; p += 32) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float m = (slot + 32 * i < HW) ? 1.f : 0.f;
+        s.x += m * v[i].x; s.y += m * v[i].y; s.z += m * v[i].z; s.w += m * v[i].w;
     }
-    red[tid] = s;
-    __syncthreads();
-    for (int st = 128; st >= 8; st >>= 1) {
-        if (tid < st) {
-            float4 o = red[tid + st];
-            float4 m = red[tid];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            red[tid] = m;
-        }
-        __syncthreads();
-    }
-    float4 mu = red[tid & 7];
+    float4 mu = block_sum_by_quad(s, red, tid);
     const float inv = 1.0f / (float)HW;
     mu.x *= inv; mu.y *= inv; mu.z *= inv; mu.w *= inv;
-    __syncthreads();
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = slot; p < HW; p += 32) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
-        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
-        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float m = (slot + 32 * i < HW) ? 1.f : 0.f;
+        const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+        q.x += m * dx * dx; q.y += m * dy * dy; q.z += m * dz * dz; q.w += m * dw * dw;
     }
-    red[tid] = q;
-    __syncthreads();
-    for (int st = 128; st >= 8; st >>= 1) {
-        if (tid < st) {
-            float4 o = red[tid + st];
-            float4 m = red[tid];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            red[tid] = m;
-        }
-        __syncthreads();
-    }
+    const float4 var = block_sum_by_quad(q, red, tid);
     if (tid < 8) {
-        const float4 var = red[tid];
         if (S > 1) {
             float* dst = part + (((size_t)b * S + blockIdx.z) * 2) * C + c0 + cq;
             *reinterpret_cast<float4*>(dst) = mu;
@@ -261,12 +263,21 @@ __global__ void k_in_stats_merge(const float* __restrict__ part, float* __restri
 
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
                            int C, hipStream_t stream) {
-    // enough blocks to fill the chip, at least 64 pixels per slice, slices of equal size
+    constexpr long min_blocks = 128;  // measured on MI355X: more slices than this cost more in the merge than they gain
+    // a block holds at most 1024 pixels x 32 channels in registers; more slices only while the grid is
+    // small and the slices stay equal and at least 64 pixels long
     int S = 1;
-    while (part && S < 32 && (long)B * (C / 32) * S < 2048 && HW % (2 * S) == 0 && HW / (2 * S) >= 64 &&
-           (size_t)B * 2 * S * 2 * C <= part_floats)
+    while (HW / S > 1024 || HW % S) {
         S *= 2;
-    hipLaunchKernelGGL(k_in_stats, dim3(B, C / 32, S), dim3(256), 0, stream, x, mean, rstd, part, HW, C);
+        if (S > 32) return hipErrorInvalidValue;
+    }
+    while (part && S < 32 && (long)B * (C / 32) * S < min_blocks && HW % (2 * S) == 0 && HW / (2 * S) >= 64) S *= 2;
+    if (S > 1 && (!part || (size_t)B * S * 2 * C > part_floats)) return hipErrorInvalidValue;
+    const int per = (HW / S + 31) / 32;
+    const dim3 grid(B, C / 32, S);
+    if (per <= 2) hipLaunchKernelGGL(k_in_stats<2>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
+    else if (per <= 8) hipLaunchKernelGGL(k_in_stats<8>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
+    else hipLaunchKernelGGL(k_in_stats<32>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
     if (S > 1)
         hipLaunchKernelGGL(k_in_stats_merge, dim3((B * C + 255) / 256), dim3(256), 0, stream, part, mean, rstd, B * C, C, S,
                            HW / S);
