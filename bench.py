@@ -69,6 +69,19 @@ def unet_flops_per_image(size, in_ch):
     return fl
 
 
+def flash_traffic_per_launch(workload, batch):
+    """HBM bytes per k_flash_hd16 launch from the committed PMC measurement (rocprofv3 --pmc FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE, separate passes: tools/pmc_traffic.sh), averaged like `achieved` over the
+    launches of one UNet evaluation (two at L=1024, two at L=256).  Only measured for C3 at batch 64."""
+    path = os.path.join(ROOT, "profiles", "r01_flash_traffic.json")
+    if workload != "c3" or batch != 64 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        t = json.load(fh)["k_flash_hd16"]
+    per = [t[k]["read_bytes"] + t[k]["write_bytes"] for k in ("L1024_B64", "L256_B64")]
+    return sum(per) / len(per)
+
+
 def build_model(w, seed):
     size = w["size"]
     if w["cond"]:
@@ -209,7 +222,9 @@ def main():
                 "peak": FP32_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP32_MATRIX_PEAK_TFLOPS) if achieved else None,
-                "traffic": None,
+                "traffic": flash_traffic_per_launch(args.workload, B),
+                "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.txt; algorithmic Q+K+V+O = "
+                                f"{(4 * 64 * 64 * (1024 + 256) * 4) / 2:.0f})" if (args.workload == "c3" and B == 64) else None,
                 "launches": kern_launches,
                 "avg_launch_us": (1e3 * kern_ms / kern_launches) if kern_launches else None,
                 "algorithmic_flops_per_launch": (kern_flops / kern_launches) if kern_launches else None,
