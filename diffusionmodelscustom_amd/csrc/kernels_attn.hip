@@ -69,18 +69,22 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         qf[t].w *= scale_log2e;
     }
 
-    // Online softmax with a lazily updated reference: mref[t] is subtracted from the scores by loading
-    // -mref into the accumulators before the QK^T products, so the common case needs no per-score
+    // Online softmax with a lazily updated reference: the reference is subtracted from the scores by feeding
+    // its negative to the QK^T products as their C operand, so the common case needs no per-score
     // arithmetic before exp2.  The reference moves only on the first tile (to that tile's row maximum)
     // and when a score exceeds it by more than 2^RESCALE_LOG2 (fp32 has the headroom: probabilities
     // are then at most 2^24 relative to the reference and sums over 4096 keys stay far below 2^127).
-    f32x4 ot[QT];
-    float mref[QT], lrun[QT];
+    // negm[t] = -reference in all four registers: it is the C operand of the first QK^T product of every score
+    // tile (no per-tile accumulator initialisation); lrun[t] keeps the row sum as two partial sums so that the
+    // probabilities are added two at a time (packed fp32 adds).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 ot[QT], negm[QT];
+    f32x2 lrun[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         ot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mref[t] = 0.f;
-        lrun[t] = 0.f;
+        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lrun[t] = f32x2{0.f, 0.f};
     }
 
     // staging: 64 keys x 16 floats = 256 float4 per operand, one per thread
@@ -110,9 +114,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    f32x4 a = f32x4{-mref[t], -mref[t], -mref[t], -mref[t]};
+                    f32x4 a = negm[t];
                     if (!(ABL & 8)) {
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, negm[t], 0, 0, 0);
                         a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
                         a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
                         a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     m = fmaxf(m, __shfl_xor(m, 32));  // the four lanes that share a query agree on the shift
                     const float delta = first ? m : ((m > RESCALE_LOG2) ? m : 0.f);
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                    mref[t] += delta;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) negm[t][r] -= delta;
                     lrun[t] *= alpha;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
@@ -154,7 +159,6 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float p0 = (ABL & 1) ? s[t][j][0] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][0]);
@@ -162,10 +166,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     const float p2 = (ABL & 1) ? s[t][j][2] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][2]);
                     const float p3 = (ABL & 1) ? s[t][j][3] * 0.5f : __builtin_amdgcn_exp2f(s[t][j][3]);
                     s[t][j] = f32x4{p0, p1, p2, p3};
-                    ps0 += p0 + p2;
-                    ps1 += p1 + p3;
+                    lrun[t] += f32x2{p0, p1};
+                    lrun[t] += f32x2{p2, p3};
                 }
-                lrun[t] += ps0 + ps1;
             }
             // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[key 4g + r][d]), B = P (the S^T registers)
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int C = heads * 16;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        float l = lrun[t];
+        float l = lrun[t][0] + lrun[t][1];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
