@@ -61,8 +61,22 @@ __device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias,
     return v;
 }
 
+// Timing ablations (tune_igemm builds this file with -DDANRA_IGEMM_DEBUG=1; results are then wrong when
+// p.debug != 0).  In the library build the flags are compiled out of the loop.
+#ifndef DANRA_IGEMM_DEBUG
+#define DANRA_IGEMM_DEBUG 0
+#endif
+
+constexpr int A_CONV_IN = 3;  // kernel-internal: A_CONV with InstanceNorm applied on load
+constexpr int A_GEMM_LN = 4;  // kernel-internal: A_GEMM with LayerNorm applied on load
+
 template <int BM, int KW, int AMODE>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
+    constexpr bool CONV = (AMODE == A_CONV || AMODE == A_CONV_IN);
+    constexpr bool NORM = (AMODE == A_CONV_IN);
+    constexpr bool GEMM = (AMODE == A_GEMM || AMODE == A_GEMM_LN);
+    constexpr bool LNORM = (AMODE == A_GEMM_LN);
+    const int dbg = DANRA_IGEMM_DEBUG ? p.debug : 0;
     constexpr int T = 256 * KW;
     constexpr int BK = (KW == 4) ? 64 : 32;
     constexpr int LDK = BK + 4;
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         abase[j] = rm[j] * p.lda + c4;
         asafe[j] = abase[j];
         nbase[j] = 0;
-        if (AMODE != A_GEMM) {
+        if (!GEMM) {
             const int b = rm[j] / howo;
             const int r = rm[j] - b * howo;
             const int oy = r / p.Wo;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
 
     // ---- LayerNorm statistics of this thread's rows (two-pass, fp32) over the whole K = channel
     //      count: TPR lanes share a row, same thread->row mapping as the staging loads
-    if (p.ln) {
+    if (LNORM) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const float* src = p.A + abase[j];
@@ -191,49 +205,53 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     // redundant by design: it keeps every load unconditional.
     const int n_chunks = c_end - c_begin;
     // conv: (kh, kw, cc) of the chunk being loaded, advanced incrementally (wave-uniform scalars)
-    int t_kh = 0, t_kw = 0, t_cc = 0;
-    if (AMODE == A_CONV) {
+    //       and delta = the tap's element offset inside the NHWC window, (kh*Wi + kw)*Cin + cc
+    int t_kh = 0, t_kw = 0, t_cc = 0, delta = 0;
+    if (CONV) {
         const int k0 = c_begin * BK;
         const int tap = k0 / p.Cin;
         t_cc = k0 - tap * p.Cin;
         t_kh = tap / p.KW;
         t_kw = tap - t_kh * p.KW;
+        delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
     }
+    const int row_jump = (p.Wi - p.KW) * p.Cin;
     for (int it = 0; it <= n_chunks; ++it) {
-        const int k0 = (p.debug & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;
+        const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;
         // -- load phase: issue global loads only; nothing here may consume a loaded value
         float4 araw[AR], amu[AR], ars[AR], breg[BR];
         unsigned okmask = 0;  // 4 bits per staged row: which of the four elements are real data
-        if (AMODE == A_GEMM) {
+        if (GEMM) {
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
-                araw[j] = *reinterpret_cast<const float4*>(p.A + abase[j] + k0);
+                araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)(abase[j] + k0));
                 okmask |= (rvalid[j] ? 0xFu : 0u) << (4 * j);
             }
-        } else if (AMODE == A_CONV) {
-            const int delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
+        } else if (CONV) {
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const bool ok = rvalid[j] && (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi &&
                                 (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
                 const int off = ok ? abase[j] + delta : asafe[j] + t_cc;
-                araw[j] = *reinterpret_cast<const float4*>(p.A + off);
+                araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)off);
                 okmask |= (ok ? 0xFu : 0u) << (4 * j);
             }
-            if (p.nmean) {
+            if (NORM) {
 #pragma unroll
                 for (int j = 0; j < AR; ++j) {
-                    amu[j] = *reinterpret_cast<const float4*>(p.nmean + nbase[j] + t_cc);
-                    ars[j] = *reinterpret_cast<const float4*>(p.nrstd + nbase[j] + t_cc);
+                    amu[j] = *reinterpret_cast<const float4*>(p.nmean + (unsigned)(nbase[j] + t_cc));
+                    ars[j] = *reinterpret_cast<const float4*>(p.nrstd + (unsigned)(nbase[j] + t_cc));
                 }
             }
-            if (it + 1 < n_chunks && !(p.debug & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
+            if (it + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
                 t_cc += BK;
+                delta += BK;  // channels, then the next pixel of the row, are contiguous in NHWC
                 if (t_cc >= p.Cin) {
                     t_cc = 0;
                     if (++t_kw == p.KW) {
                         t_kw = 0;
                         ++t_kh;
+                        delta += row_jump;
                     }
                 }
             }
@@ -259,12 +277,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + wbase[j] + k0);
+        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + (unsigned)(wbase[j] + k0));
 
         // keep the scheduler from hoisting the store phase's ALU (and with it the wait for the loads)
         // above the matrix work
         __builtin_amdgcn_sched_barrier(0);
-        if (it > 0 && !(p.debug & 2)) {
+        if (it > 0 && !(dbg & 2)) {
             const int buf = (it - 1) & 1;
             const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
             const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
@@ -287,19 +305,19 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(p.debug & 4) || it == 0) {   // -- store phase: normalise / zero-fill the staged operand, then write it to LDS
+        if (!(dbg & 4) || it == 0) {   // -- store phase: normalise / zero-fill the staged operand, then write it to LDS
             float* As = As0 + (it & 1) * BM * LDK;
             float* Bs = Bs0 + (it & 1) * BN * LDK;
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 float4 v = araw[j];
-                if (AMODE == A_GEMM && p.ln) {
+                if (LNORM) {
                     v.x = (v.x - rmean[j]) * rrstd[j];
                     v.y = (v.y - rmean[j]) * rrstd[j];
                     v.z = (v.z - rmean[j]) * rrstd[j];
                     v.w = (v.w - rmean[j]) * rrstd[j];
                 }
-                if (AMODE == A_CONV && p.nmean) {
+                if (NORM) {
                     v.x = (v.x - amu[j].x) * ars[j].x;
                     v.y = (v.y - amu[j].y) * ars[j].y;
                     v.z = (v.z - amu[j].z) * ars[j].z;
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
 #pragma unroll
             for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
         }
-        if (!(p.debug & 4) || it == 0) __syncthreads();
+        if (!(dbg & 4) || it == 0) __syncthreads();
     }
 
     // ---- sum the KW partial accumulators (fixed order: k-part 0, 1, 2, 3)
@@ -580,7 +598,9 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
 #define DANRA_LAUNCH_IGEMM(BM_, KW_)                                                                      \
     do {                                                                                                  \
         dim3 grid((a.M + BM_ - 1) / BM_, a.N / BN, ks);                                                   \
-        if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM>), grid, dim3(256 * KW_), 0, stream, a);        \
+        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM_LN>), grid, dim3(256 * KW_), 0, stream, a); \
+        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else if (a.a_mode == A_CONV && a.nmean) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV_IN>), grid, dim3(256 * KW_), 0, stream, a); \
         else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV>), grid, dim3(256 * KW_), 0, stream, a);   \
         else hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1>), grid, dim3(256 * KW_), 0, stream, a);       \
     } while (0)
