@@ -78,7 +78,7 @@ struct Workspace {
     void* base = nullptr;
     size_t bytes = 0;
     float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
-    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part;
+    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part, *zeros;
     size_t stats_part_floats = 0;
     size_t partial_floats = 0;
     // sampler: device-resident loop state, per-timestep update coefficients, private copies of the inputs
@@ -394,6 +394,7 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         ws.stats_part = bp.take(ws.stats_part_floats);
         ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
         ws.partial = bp.take(ws.partial_floats);
+        ws.zeros = bp.take(64);
         if (!pass) {
             ws.bytes = bp.off;
             if (hipMalloc(&ws.base, ws.bytes) != hipSuccess) {
@@ -402,6 +403,7 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
             }
         }
     }
+    HIP_TRY(hipMemset(ws.zeros, 0, 64 * sizeof(float)));
     ws.B = B; ws.H = H; ws.W = W;
     return DANRA_OK;
 }
@@ -442,7 +444,7 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     IGemmArgs a = blank_args();
     const int Ho = (Hi + 2 * c.pad - c.KH) / c.stride + 1, Wo = (Wi + 2 * c.pad - c.KW) / c.stride + 1;
     a.A = in; a.W = c.w; a.bias = c.bias; a.res = res; a.tbias = tbias; a.out = out;
-    a.nmean = nmean; a.nrstd = nrstd;
+    a.nmean = nmean; a.nrstd = nrstd; a.zeros = h->ws.zeros;
     a.M = B * Ho * Wo; a.N = c.Cout; a.K = c.KH * c.KW * c.Cin;
     a.a_mode = A_CONV;
     a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;

@@ -26,6 +26,7 @@ struct IGemmArgs {
     const float* tbias;
     const float* nmean;
     const float* nrstd;
+    const float* zeros;  // >= 16 bytes of zeros: what a convolution's padding taps read
     float* out;
     float* partial;  // split-K slabs [ksplit][M][N]
     int M, N, K;

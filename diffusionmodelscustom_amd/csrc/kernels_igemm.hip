@@ -126,10 +126,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int c4 = (tid % TPR) * 4;
     // Row j of this thread: 32-bit element offsets (every tensor of the network is < 2^31 elements).
     //   conv : abase = offset of tap (0,0) of the row's window (may point before the row's image for
-    //          padded taps: only used when the tap is in bounds); asafe = the window's centre pixel
-    //          (always in bounds), read instead of an out-of-bounds tap and then zeroed
+    //          padded taps: only used when the tap is in bounds)
     //   gemm : abase = m*lda + c4
-    int rb[AR], riy[AR], rix[AR], rm[AR], abase[AR], asafe[AR], nbase[AR];
+    int rb[AR], riy[AR], rix[AR], rm[AR], abase[AR], nbase[AR];
     bool rvalid[AR];
     float rmean[AR], rrstd[AR];
     const int howo = p.Ho * p.Wo;
@@ -144,7 +143,6 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         riy[j] = 0;
         rix[j] = 0;
         abase[j] = rm[j] * p.lda + c4;
-        asafe[j] = abase[j];
         nbase[j] = 0;
         if (!GEMM) {
             const int b = rm[j] / howo;
@@ -155,7 +153,6 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             riy[j] = oy * p.stride - p.pad;
             rix[j] = ox * p.stride - p.pad;
             abase[j] = ((b * p.Hi + riy[j]) * p.Wi + rix[j]) * p.Cin + c4;
-            asafe[j] = ((b * p.Hi + riy[j] + p.pad) * p.Wi + rix[j] + p.pad) * p.Cin + c4;
             nbase[j] = b * p.Cin + c4;
         }
     }
@@ -220,27 +217,23 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;
         // -- load phase: issue global loads only; nothing here may consume a loaded value
         float4 araw[AR], amu[AR], ars[AR], breg[BR];
-        unsigned okmask = 0;  // 4 bits per staged row: which of the four elements are real data
+        unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
         if (GEMM) {
+            // rows past M re-read row M-1: they only feed output rows that are never stored
 #pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)(abase[j] + k0));
-                okmask |= (rvalid[j] ? 0xFu : 0u) << (4 * j);
-            }
+            for (int j = 0; j < AR; ++j) araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)(abase[j] + k0));
         } else if (CONV) {
+            // a padding tap reads a block of zeros instead (pointer select, the load itself stays unconditional);
+            // with InstanceNorm on load its 1/std comes from the zeros too, so (0 - mean) * 0 = 0 needs no select
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
-                const bool ok = rvalid[j] && (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi &&
-                                (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
-                const int off = ok ? abase[j] + delta : asafe[j] + t_cc;
-                araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)off);
-                okmask |= (ok ? 0xFu : 0u) << (4 * j);
-            }
-            if (NORM) {
-#pragma unroll
-                for (int j = 0; j < AR; ++j) {
+                const bool ok = (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi && (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
+                const float* src = ok ? p.A + (unsigned)(abase[j] + delta) : p.zeros;
+                araw[j] = *reinterpret_cast<const float4*>(src);
+                if (NORM) {
+                    const float* rs = ok ? p.nrstd + (unsigned)(nbase[j] + t_cc) : p.zeros;
                     amu[j] = *reinterpret_cast<const float4*>(p.nmean + (unsigned)(nbase[j] + t_cc));
-                    ars[j] = *reinterpret_cast<const float4*>(p.nrstd + (unsigned)(nbase[j] + t_cc));
+                    ars[j] = *reinterpret_cast<const float4*>(rs);
                 }
             }
             if (it + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
@@ -323,11 +316,13 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                     v.z = (v.z - amu[j].z) * ars[j].z;
                     v.w = (v.w - amu[j].w) * ars[j].w;
                 }
-                const unsigned m4 = okmask >> (4 * j);
-                v.x = (m4 & 1u) ? v.x : 0.f;
-                v.y = (m4 & 2u) ? v.y : 0.f;
-                v.z = (m4 & 4u) ? v.z : 0.f;
-                v.w = (m4 & 8u) ? v.w : 0.f;
+                if (AMODE == A_CONV1) {
+                    const unsigned m4 = okmask >> (4 * j);
+                    v.x = (m4 & 1u) ? v.x : 0.f;
+                    v.y = (m4 & 2u) ? v.y : 0.f;
+                    v.z = (m4 & 4u) ? v.z : 0.f;
+                    v.w = (m4 & 8u) ? v.w : 0.f;
+                }
                 *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
             }
 #pragma unroll
@@ -558,6 +553,7 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const bool vec4 = a.ldc % 4 == 0 && (a.st_mode != ST_QKV || a.qkv_hd % 4 == 0) && (a.st_mode != ST_CONVT || a.ct_C % 4 == 0) &&
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
     if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
+    if (a.a_mode == A_CONV && !a.zeros) return hipErrorInvalidValue;
     if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
         a.M >= 32768 && !a.tbias && !a.res) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs

@@ -61,6 +61,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&W, (size_t)16 << 20));
     CK(hipMalloc(&bias, 1 << 16));
     CK(hipMalloc(&partial, (size_t)64 << 20));
+    float* zeros;
+    CK(hipMalloc(&zeros, 256));
+    CK(hipMemset(zeros, 0, 256));
     std::vector<float> h(big);
     srand(1);
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
@@ -76,7 +79,7 @@ int main(int argc, char** argv) {
         const Shape& s = shapes[si];
         IGemmArgs a;
         memset(&a, 0, sizeof(a));
-        a.A = A; a.W = W; a.bias = bias; a.out = out; a.partial = partial; a.rows_per_img = 1;
+        a.A = A; a.W = W; a.bias = bias; a.out = out; a.partial = partial; a.zeros = zeros; a.rows_per_img = 1;
         if (s.mode == A_CONV) {
             const int Ho = (s.Hi + 2 * s.pad - s.k) / s.stride + 1, Wo = (s.Wi + 2 * s.pad - s.k) / s.stride + 1;
             a.M = s.B * Ho * Wo; a.N = s.Cout; a.K = s.k * s.k * s.Cin; a.a_mode = A_CONV;
