@@ -347,3 +347,20 @@ def test_sampler_loop_equals_its_parts(cond64, dev):
         else:
             x = ops.ddpm_update(x, eps, None, float(c1), float(c2), float(c3))
     assert torch.equal(got, x)
+
+
+def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
+    """B = 33 at 64x64 puts 33792 tokens through the K=64 row-stationary GEMM (QKV at L=1024, final transposed
+    convolution) with a partly empty last workgroup; every image must equal its own B = 1 evaluation."""
+    model, _, _ = cond64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 33, 64, seed=17).items()}
+    t = torch.arange(33, device=dev) * 30 + 1
+    with torch.no_grad():
+        full = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        for i in (0, 16, 32):
+            one = model(inp["x"][i:i + 1], t[i:i + 1], inp["y"][i:i + 1], inp["cond_img"][i:i + 1],
+                        inp["lsm_cond"][i:i + 1], inp["topo_cond"][i:i + 1])
+            assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
+        want = cpu_ref.unet_forward(state_dict_cpu(model), inp["x"][32:33].cpu(), t[32:33].cpu(), inp["y"][32:33].cpu(),
+                                    inp["cond_img"][32:33].cpu(), inp["lsm_cond"][32:33].cpu(), inp["topo_cond"][32:33].cpu())
+    assert rel_err(full[32:33].cpu(), want) < TOL_FWD
