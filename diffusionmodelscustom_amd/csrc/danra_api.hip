@@ -766,6 +766,17 @@ int danra_ddpm_update_philox(float* x, const float* eps, float c1, float c2, flo
     return DANRA_OK;
 }
 
+int danra_noise_image(const float* x, const int64_t* t, const float* alpha_hat, int T, float* noisy, float* noise, int B,
+                      size_t per_image, int noise_mode, uint64_t seed, uint64_t offset, void* stream) {
+    if (!x || !t || !alpha_hat || !noisy || !noise) return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || T <= 0 || per_image == 0 || per_image % 4)
+        return fail(DANRA_EINVAL, "B=%d T=%d per_image=%zu: per_image must be a positive multiple of 4", B, T, per_image);
+    if (noise_mode != DANRA_NOISE_HOST && noise_mode != DANRA_NOISE_PHILOX) return fail(DANRA_EINVAL, "unknown noise mode");
+    HIP_TRY(launch_noise_image(x, t, alpha_hat, T, noisy, noise, B, per_image, noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed,
+                               offset, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,

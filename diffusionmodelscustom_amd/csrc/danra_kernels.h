@@ -95,6 +95,9 @@ hipError_t launch_final_conv(const float* x, const float* mean, const float* rst
                              float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
 hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
                               size_t n, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
+// noisy = sqrt(alpha_hat[t_b]) * x + sqrt(1 - alpha_hat[t_b]) * z; z read from `noise` or drawn (and written there)
+hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alpha_hat, int T, float* noisy, float* noise,
+                              int B, size_t per_image, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 

@@ -603,6 +603,61 @@ hipError_t launch_ddpm_update_state(float* x, const float* eps, const float4* co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward process q(x_t | x_0): noisy = sqrt(ah[t_b]) * x + sqrt(1 - ah[t_b]) * z, with z either supplied or drawn
+// here (Philox, written back so that the training loss can use it).  Two products and one sum, each rounded to
+// fp32 like the three tensor operations of the reference; the square roots are correctly rounded.
+__device__ __forceinline__ float noise_one(float x, float z, float keep, float spread) {
+#pragma clang fp contract(off)
+    const float a = keep * x;
+    const float b = spread * z;
+    return a + b;
+}
+
+__global__ __launch_bounds__(256) void k_noise_image(const float* __restrict__ x, const int64_t* __restrict__ t,
+                                                     const float* __restrict__ alpha_hat, int T, float* __restrict__ noisy,
+                                                     float* __restrict__ noise, size_t per4, size_t total4, int philox,
+                                                     uint64_t seed, uint64_t offset) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per4;
+        long long ti = t[b];
+        ti = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
+        const float ah = alpha_hat[ti];
+        const float keep = sqrtf(ah);
+        const float spread = sqrtf(1.0f - ah);
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 z;
+        if (philox) {
+            uint32_t r[4];
+            philox4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                    (uint32_t)(seed >> 32), r);
+            box_muller(r[0], r[1], z.x, z.y);
+            box_muller(r[2], r[3], z.z, z.w);
+            reinterpret_cast<float4*>(noise)[i] = z;
+        } else {
+            z = reinterpret_cast<const float4*>(noise)[i];
+        }
+        float4 o;
+        o.x = noise_one(xv.x, z.x, keep, spread);
+        o.y = noise_one(xv.y, z.y, keep, spread);
+        o.z = noise_one(xv.z, z.z, keep, spread);
+        o.w = noise_one(xv.w, z.w, keep, spread);
+        reinterpret_cast<float4*>(noisy)[i] = o;
+    }
+}
+
+hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alpha_hat, int T, float* noisy, float* noise,
+                              int B, size_t per_image, int philox, uint64_t seed, uint64_t offset, hipStream_t stream) {
+    if (per_image % 4) return hipErrorInvalidValue;
+    const size_t per4 = per_image / 4, total4 = per4 * B;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_noise_image, dim3(blocks), dim3(256), 0, stream, x, t, alpha_hat, T, noisy, noise, per4, total4,
+                       philox, seed, offset);
+    return hipGetLastError();
+}
+
 __global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise) {
     if (threadIdx.x == 0) {
         s->t_fwd = t_start;

@@ -50,11 +50,19 @@ class DiffusionUtils:
     def sampleTimesteps(self, size: int):
         return torch.randint(low=1, high=self.n_timesteps, size=(size,)).to(self.device)
 
-    def noiseImage(self, x: torch.Tensor, t: torch.LongTensor):
+    def noiseImage(self, x: torch.Tensor, t: torch.LongTensor, noise: torch.Tensor = None):
+        """Forward process (reference diffusion:85-103): returns (noisy image, the noise that was added).
+        On a CUDA fp32 batch whose per-image size is a multiple of 4 this is one HIP kernel, the Gaussian draws made
+        in-kernel (Philox) unless `noise` supplies them; elsewhere the reference's torch expressions."""
         assert len(x.shape) == 4, 'x must be a 4D tensor'
+        if (x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and x[0].numel() % 4 == 0
+                and self.alpha_hat.device == x.device):
+            from . import hip_engine
+            return hip_engine.noise_image(x, t, self.alpha_hat, noise=noise, seed=self._philox_seed(), offset=0)
         keep = torch.sqrt(self.alpha_hat[t])[:, None, None, None]
         spread = torch.sqrt(1 - self.alpha_hat[t])[:, None, None, None]
-        noise = torch.randn_like(x).to(self.device)
+        if noise is None:
+            noise = torch.randn_like(x).to(self.device)
         return (keep * x) + (spread * noise), noise
 
     # ------------------------------------------------------------------ reverse process

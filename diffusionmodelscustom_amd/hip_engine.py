@@ -49,6 +49,8 @@ _SIGNATURES = {
                                                 ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_sample": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_int, _P, _P]),
+    "danra_noise_image": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
+                                         ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
@@ -126,6 +128,29 @@ def reference_freq_tables(dim):
     enc = 1.0 / (1000 ** (torch.arange(0, dim, 2).float() / dim))
     dec = torch.tensor([10000 ** (2 * i / dim) for i in range(dim // 2)], dtype=torch.float64).float()
     return enc.contiguous(), dec.contiguous()
+
+
+def noise_image(x, t, alpha_hat, noise=None, seed=0, offset=0):
+    """DiffusionUtils.noiseImage on the device: returns (noisy, noise).  `noise` given = the Gaussian draws to use
+    (parity mode); otherwise they are drawn in the kernel from (seed, offset) and returned."""
+    lib = load_library()
+    x = _f32(x, "x")
+    B = x.shape[0]
+    per_image = x[0].numel()
+    tt = _i64(t, "t")
+    ah = _f32(alpha_hat, "alpha_hat")
+    noisy = torch.empty_like(x)
+    if noise is None:
+        mode, z = NOISE_PHILOX, torch.empty_like(x)
+    else:
+        mode, z = NOISE_HOST, _f32(noise, "noise")
+    with torch.cuda.device(x.device):
+        _check(lib, lib.danra_noise_image(_ptr(x), _ptr(tt), _ptr(ah), int(ah.numel()), _ptr(noisy), _ptr(z), B,
+                                          ctypes.c_size_t(per_image), mode, ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                          ctypes.c_uint64(int(offset) & 0xFFFFFFFFFFFFFFFF), _stream()), "danra_noise_image")
+        for keep in (tt, ah):
+            keep.record_stream(torch.cuda.current_stream())
+    return noisy, z
 
 
 class UNetEngine:

@@ -115,6 +115,17 @@ int danra_sample(danra_handle_t h, float* x_dev, const int64_t* y_dev, const flo
                  const float* noise_dev, uint64_t seed, const int* trace_steps, int n_trace,
                  float* trace_dev, void* stream);
 
+/* Replaces DiffusionUtils.noiseImage (diffusion_DANRA_conditional.py:85-103), the forward process used by the
+ * training step: noisy = sqrt(alpha_hat[t_b]) * x + sqrt(1 - alpha_hat[t_b]) * noise for image b, every operation
+ * rounded to fp32 as torch evaluates the three tensor expressions.  alpha_hat_dev: DiffusionUtils.alpha_hat (device,
+ * T floats); t_dev: B int64 timesteps (clamped to [0, T-1]); per_image = C*H*W, a multiple of 4.
+ * DANRA_NOISE_HOST reads the Gaussian draws from noise_dev ([B, C, H, W]); DANRA_NOISE_PHILOX draws them in the
+ * kernel (Philox4x32-10 keyed by `seed`, counter = (element index / 4, offset), Box-Muller) and writes them to
+ * noise_dev, which is the second value noiseImage returns (the regression target of the loss). */
+int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alpha_hat_dev, int T, float* noisy_out,
+                      float* noise_dev, int B, size_t per_image, int noise_mode, uint64_t seed, uint64_t offset,
+                      void* stream);
+
 /* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
  * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns
  * it off), 0 enqueues every kernel of every step.  Both modes run the same kernels on the same data and

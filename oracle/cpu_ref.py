@@ -54,6 +54,14 @@ def ddpm_update(x, eps, noise, c1, c2, c3):
     return x + c3 * noise
 
 
+def noise_image(x, t, alpha_hat, noise):
+    """diffusion_DANRA_conditional.py:96-103 given the Gaussian draw: sqrt(alpha_hat[t]) * x + sqrt(1 - alpha_hat[t]) * noise,
+    per-image coefficients broadcast over (C, H, W)."""
+    keep = torch.sqrt(alpha_hat[t])[:, None, None, None]
+    spread = torch.sqrt(1 - alpha_hat[t])[:, None, None, None]
+    return (keep * x) + (spread * noise)
+
+
 # --------------------------------------------------------------------------- embeddings
 def encoder_pos_encoding(t, channels=256):
     """modules_DANRA_conditional.py:203-211,243-244: base 1000, [sin x128 | cos x128]."""

@@ -21,6 +21,9 @@ VARIANTS = {
 
 SCHEDULE_CASES = [(T, s) for T in (200, 800, 1000) for s in ("linear", "cosine")]
 EMBED_TIMESTEPS = (1, 2, 5, 137, 999)
+NOISE_IMAGE_T = 1000
+NOISE_IMAGE_SHAPE = (6, 1, 32, 32)
+NOISE_IMAGE_TIMESTEPS = (1, 2, 137, 500, 998, 999)
 FORWARD_TIMESTEPS = (1, 500, 999)
 ATTN_LEVELS = ((0, 64, 32), (1, 64, 16), (2, 128, 8), (3, 256, 4), (4, 512, 2))  # (level, C, side)
 CHAIN_CASES = {"T50": dict(T=50, B=2), "T200": dict(T=200, B=2), "T1000": dict(T=1000, B=1)}

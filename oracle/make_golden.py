@@ -53,14 +53,35 @@ def save(name, **arrays):
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def gen_noise_image(ref_diffusion):
+    """G7: the forward process DiffusionUtils.noiseImage (diffusion_DANRA_conditional.py:85-103) for both schedules;
+    the reference's own randn_like draw is stored, so that a restatement is checked given the same noise."""
+    out = {}
+    for s in ("linear", "cosine"):
+        du = ref_diffusion.DiffusionUtils(gs.NOISE_IMAGE_T, gs.BETA_MIN, gs.BETA_MAX, "cpu", s)
+        x = gs.randn(700, *gs.NOISE_IMAGE_SHAPE)
+        t = torch.tensor(gs.NOISE_IMAGE_TIMESTEPS, dtype=torch.long)
+        torch.manual_seed(gs.SEED + 7)
+        noisy, noise = du.noiseImage(x, t)
+        out[f"{s}_noisy"] = noisy.numpy()
+        out[f"{s}_noise"] = noise.numpy()
+    out["t"] = t.numpy()
+    save("noise_image", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the T=1000 chain")
     ap.add_argument("--only-state-dict", action="store_true", help="write only state_dict.json")
+    ap.add_argument("--only-noise-image", action="store_true", help="write only noise_image.npz")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(gs.SEED)
     ref_modules, ref_diffusion = import_reference()
+
+    if args.only_noise_image:
+        gen_noise_image(ref_diffusion)
+        return
 
     # G0: the checkpoint contract: state_dict keys (in registration order) and shapes per variant
     contract = {}

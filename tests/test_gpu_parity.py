@@ -364,3 +364,33 @@ def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
         want = cpu_ref.unet_forward(state_dict_cpu(model), inp["x"][32:33].cpu(), t[32:33].cpu(), inp["y"][32:33].cpu(),
                                     inp["cond_img"][32:33].cpu(), inp["lsm_cond"][32:33].cpu(), inp["topo_cond"][32:33].cpu())
     assert rel_err(full[32:33].cpu(), want) < TOL_FWD
+
+
+@pytest.mark.parametrize("sched", ["linear", "cosine"])
+def test_noise_image_bit_exact_and_philox(golden, dev, sched):
+    """Forward process kernel (next-row f1, danra_noise_image): bit-exact against the reference's noiseImage given
+    its draw; the in-kernel draw is returned, standard normal, reproducible in the seed and consistent with the
+    noisy image it produced."""
+    from diffusionmodelscustom_amd import DiffusionUtils, hip_engine
+    g = golden("noise_image")
+    du = DiffusionUtils(gs.NOISE_IMAGE_T, gs.BETA_MIN, gs.BETA_MAX, dev, sched)
+    sc = golden("schedule")
+    alpha_hat = torch.from_numpy(sc[f"{sched}_{gs.NOISE_IMAGE_T}_alpha_hat"]).to(dev)  # the reference's own table
+    x = gs.randn(700, *gs.NOISE_IMAGE_SHAPE).to(dev)
+    t = torch.from_numpy(g["t"]).to(dev)
+    noise = torch.from_numpy(g[f"{sched}_noise"]).to(dev)
+    noisy, z = hip_engine.noise_image(x, t, alpha_hat, noise=noise)
+    assert np.array_equal(noisy.cpu().numpy(), g[f"{sched}_noisy"]) and z.data_ptr() == noise.data_ptr()
+    # through the class, Philox draws
+    xb = torch.randn(64, 1, 64, 64, device=dev)
+    tb = du.sampleTimesteps(64)
+    du.noise_seed = 5
+    n1, z1 = du.noiseImage(xb, tb)
+    n2, z2 = du.noiseImage(xb, tb)
+    du.noise_seed = 6
+    n3, z3 = du.noiseImage(xb, tb)
+    assert torch.equal(n1, n2) and torch.equal(z1, z2) and not torch.equal(z1, z3)
+    assert abs(z1.mean().item()) < 0.01 and abs(z1.std().item() - 1.0) < 0.01
+    keep = torch.sqrt(du.alpha_hat[tb])[:, None, None, None]
+    spread = torch.sqrt(1 - du.alpha_hat[tb])[:, None, None, None]
+    assert torch.equal(n1, (keep * xb) + (spread * z1))

@@ -139,3 +139,19 @@ def test_cuda_inference_without_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(hip_engine, "_LIB_PATH", "/nonexistent/libdanra_hip.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         hip_engine.load_library()
+
+
+def test_noise_image_cpu_path_matches_golden(golden):
+    """DiffusionUtils.noiseImage on CPU tensors is the reference's expression (and draws with torch's generator)."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    g = golden("noise_image")
+    du = DiffusionUtils(gs.NOISE_IMAGE_T, gs.BETA_MIN, gs.BETA_MAX, "cpu", "linear")
+    x = gs.randn(700, *gs.NOISE_IMAGE_SHAPE)
+    t = torch.from_numpy(g["t"])
+    torch.manual_seed(gs.SEED + 7)
+    noisy, noise = du.noiseImage(x, t)
+    assert np.array_equal(noise.numpy(), g["linear_noise"]) and np.array_equal(noisy.numpy(), g["linear_noisy"])
+    noisy2, noise2 = du.noiseImage(x, t, noise=noise)
+    assert torch.equal(noisy2, noisy) and noise2 is noise
+    with pytest.raises(AssertionError, match="x must be a 4D tensor"):
+        du.noiseImage(x[0], t)

@@ -117,3 +117,15 @@ def test_update_matches_reference_statements():
         want = (1 / torch.sqrt(a)) * (x - ((1 - a) / torch.sqrt(1 - ah)) * eps)
         want = want + torch.sqrt(b) * z
         assert torch.equal(cpu_ref.ddpm_update(x, eps, z, c1, c2, c3), want)
+
+
+@pytest.mark.parametrize("sched", ["linear", "cosine"])
+def test_noise_image_bit_exact(golden, sched):
+    """Forward process (next-row f1): the restatement reproduces the reference's noiseImage given its own draw."""
+    g = golden("noise_image")
+    sc = golden("schedule")
+    alpha_hat = torch.from_numpy(sc[f"{sched}_{gs.NOISE_IMAGE_T}_alpha_hat"])
+    x = gs.randn(700, *gs.NOISE_IMAGE_SHAPE)
+    t = torch.from_numpy(g["t"])
+    got = cpu_ref.noise_image(x, t, alpha_hat, torch.from_numpy(g[f"{sched}_noise"]))
+    assert np.array_equal(got.numpy(), g[f"{sched}_noisy"])
