@@ -450,6 +450,9 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
     a.ldr = c.Cout; a.relu = relu; a.tb_stride = h->tb_width; a.rows_per_img = Ho * Wo;
     a.st_mode = ST_ROW; a.ldc = c.Cout;
+    // tiny maps: pixel-major rows, so that a tile's rows share their valid taps and the padding taps are skipped
+    a.pix_major = (c.KH > 1 && Ho * Wo <= 64) ? 1 : 0;
+    a.batch = B;
     if (c.Cin % 32 || c.Cout % 64) return fail(DANRA_EINVAL, "conv channels %d->%d unsupported", c.Cin, c.Cout);
     choose_split(a, h->ws);
     HIP_TRY(launch_igemm(a, st));

@@ -39,6 +39,7 @@ struct IGemmArgs {
     int qkv_C, qkv_hd, qkv_L, qkv_heads;
     long long qkv_plane;
     int ct_C, ct_H, ct_W;
+    int pix_major, batch;          // convolutions: rows ordered pixel-major (m = pixel*batch + image) when pix_major != 0
     int ksplit, chunks_per_split;  // chunks are counted 32-deep
     int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
     int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier

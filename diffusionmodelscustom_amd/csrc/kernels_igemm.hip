@@ -39,6 +39,16 @@ __device__ __forceinline__ unsigned long long row_offset(const IGemmArgs& p, int
     return (((unsigned long long)b * 2 * p.ct_H + 2 * y) * 2 * p.ct_W + 2 * x) * p.ct_C;
 }
 
+// Row m of the GEMM -> row of the output tensor.  Convolutions on tiny feature maps walk their rows pixel-major
+// (m = pixel * batch + image), so that the rows of a tile share one output position and with it the set of
+// kernel taps that fall inside the image; everything else is image-major (identity).
+__device__ __forceinline__ int out_row(const IGemmArgs& p, int m) {
+    if (!p.pix_major) return m;
+    const int r = m / p.batch;
+    const int b = m - r * p.batch;
+    return b * (p.Ho * p.Wo) + r;
+}
+
 __device__ __forceinline__ unsigned long long col_offset(const IGemmArgs& p, int n) {
     if (p.st_mode == ST_ROW) return n;
     if (p.st_mode == ST_QKV) {
@@ -92,6 +102,8 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS];
     __shared__ unsigned long long rowOff[BM];
     __shared__ int rowImg[BM];
+    __shared__ int rowOut[BM];   // row of the output tensor (differs from m0 + row in pixel-major order)
+    __shared__ int tapBox[BM / 64][4];  // convolutions, per 64 rows: kh_lo, kh_hi, kw_lo, kw_hi = taps that touch the image for some row
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * BM * LDK;
 
@@ -105,20 +117,56 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int row0 = (BM == 128) ? tw * 32 : (tw >> 1) * 32;
     const int col0 = (BM == 128) ? 0 : (tw & 1) * 32;
 
-    const int total_chunks = p.K / BK;
-    int c_begin = 0, c_end = total_chunks;
-    if (p.ksplit > 1) {
-        const int cps = p.chunks_per_split * 32 / BK;  // the host counts 32-deep chunks
-        c_begin = blockIdx.z * cps;
-        c_end = min(total_chunks, c_begin + cps);
-    }
-
-    // ---- output row table (one or two integer divisions per row, done once per block)
+    // ---- output row table (a few integer divisions per row, done once per block)
     if (tid < BM) {
         const int m = min(m0 + tid, p.M - 1);
+        const int mo = out_row(p, m);
         int img;
-        rowOff[tid] = row_offset(p, m, img);
+        rowOff[tid] = row_offset(p, mo, img);
         rowImg[tid] = img;
+        rowOut[tid] = mo;
+        if (CONV && p.pix_major) {  // taps of this row that read inside the image: iy = oy*stride - pad + kh in [0, Hi)
+            const int r = mo - img * (p.Ho * p.Wo);
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            int lo_h = max(0, -iy0), hi_h = min(p.KH - 1, p.Hi - 1 - iy0);
+            int lo_w = max(0, -ix0), hi_w = min(p.KW - 1, p.Wi - 1 - ix0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {  // the 64 rows of this wave
+                lo_h = min(lo_h, __shfl_xor(lo_h, o));
+                hi_h = max(hi_h, __shfl_xor(hi_h, o));
+                lo_w = min(lo_w, __shfl_xor(lo_w, o));
+                hi_w = max(hi_w, __shfl_xor(hi_w, o));
+            }
+            if (lane == 0) {
+                tapBox[wave][0] = lo_h; tapBox[wave][1] = hi_h; tapBox[wave][2] = lo_w; tapBox[wave][3] = hi_w;
+            }
+        }
+    }
+    if (CONV && p.pix_major) __syncthreads();
+    // A pixel-major convolution only walks the taps of that box (on a 2x2 map that is 4 of the 9 taps of a 3x3 kernel);
+    // chunks are numbered tap-major inside the box, and split-K slices are cut from that numbering.
+    // (read through readfirstlane: values loaded from LDS are per-lane to the compiler, and the whole chunk walk
+    // would otherwise be treated as divergent)
+    int box[4] = {0, p.KH - 1, 0, p.KW - 1};
+    if (CONV && p.pix_major) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int v = tapBox[0][i];
+            if (BM == 128) v = (i & 1) ? max(v, tapBox[BM / 64 - 1][i]) : min(v, tapBox[BM / 64 - 1][i]);
+            box[i] = __builtin_amdgcn_readfirstlane(v);
+        }
+    }
+    const int kh_lo = box[0], kw_lo = box[2];
+    const int nkh = max(box[1] - kh_lo + 1, 1), nkw = max(box[3] - kw_lo + 1, 1);
+    const int cpt = CONV ? p.Cin / BK : 1;  // chunks per tap
+    const int total_chunks = CONV ? nkh * nkw * cpt : p.K / BK;
+    int c_begin = 0, c_end = total_chunks;
+    if (p.ksplit > 1) {
+        const int cps = CONV ? (total_chunks + p.ksplit - 1) / p.ksplit
+                             : p.chunks_per_split * 32 / BK;  // (GEMM, stem) the host counts 32-deep chunks
+        c_begin = min((int)blockIdx.z * cps, total_chunks);
+        c_end = min(total_chunks, c_begin + cps);
     }
 
     // ---- per-thread staging geometry
@@ -145,8 +193,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         abase[j] = rm[j] * p.lda + c4;
         nbase[j] = 0;
         if (!GEMM) {
-            const int b = rm[j] / howo;
-            const int r = rm[j] - b * howo;
+            const int mo = out_row(p, rm[j]);
+            const int b = mo / howo;
+            const int r = mo - b * howo;
             const int oy = r / p.Wo;
             const int ox = r - oy * p.Wo;
             rb[j] = b;
@@ -203,18 +252,23 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int n_chunks = c_end - c_begin;
     // conv: (kh, kw, cc) of the chunk being loaded, advanced incrementally (wave-uniform scalars)
     //       and delta = the tap's element offset inside the NHWC window, (kh*Wi + kw)*Cin + cc
-    int t_kh = 0, t_kw = 0, t_cc = 0, delta = 0;
+    //       and wk = the same position in the weight row, (kh*KW + kw)*Cin + cc
+    int t_kh = 0, t_kw = 0, t_cc = 0, delta = 0, wk = 0;
     if (CONV) {
-        const int k0 = c_begin * BK;
-        const int tap = k0 / p.Cin;
-        t_cc = k0 - tap * p.Cin;
-        t_kh = tap / p.KW;
-        t_kw = tap - t_kh * p.KW;
+        const int q = min(c_begin, total_chunks - 1);
+        const int tap = q / cpt;
+        t_cc = (q - tap * cpt) * BK;
+        t_kh = kh_lo + tap / nkw;
+        t_kw = kw_lo + tap % nkw;
         delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
+        wk = (t_kh * p.KW + t_kw) * p.Cin + t_cc;
     }
-    const int row_jump = (p.Wi - p.KW) * p.Cin;
+    const int row_jump = (p.Wi - nkw) * p.Cin;   // from the box's last tap of a row to its first tap of the next
+    const int wrow_jump = (p.KW - nkw) * p.Cin;
+    const int kw_end = kw_lo + nkw;
     for (int it = 0; it <= n_chunks; ++it) {
-        const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;
+        const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;  // GEMM, stem
+        const int wk_load = wk;
         // -- load phase: issue global loads only; nothing here may consume a loaded value
         float4 araw[AR], amu[AR], ars[AR], breg[BR];
         unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
@@ -239,12 +293,14 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             if (it + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
                 t_cc += BK;
                 delta += BK;  // channels, then the next pixel of the row, are contiguous in NHWC
+                wk += BK;     // ... and in the [kh][kw][Cin] weight row
                 if (t_cc >= p.Cin) {
                     t_cc = 0;
-                    if (++t_kw == p.KW) {
-                        t_kw = 0;
+                    if (++t_kw == kw_end) {
+                        t_kw = kw_lo;
                         ++t_kh;
                         delta += row_jump;
+                        wk += wrow_jump;
                     }
                 }
             }
@@ -270,7 +326,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + (unsigned)(wbase[j] + k0));
+        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
 
         // keep the scheduler from hoisting the store phase's ALU (and with it the wait for the loads)
         // above the matrix work
@@ -381,7 +437,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (p.res) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + n);
+            const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rowOut[row] * p.ldr + n);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -405,8 +461,9 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
             const float4 o = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + idx);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        const int m = (int)(idx / p.N);
-        const int n = (int)(idx - (size_t)m * p.N);
+        const int mt = (int)(idx / p.N);  // row of the GEMM; the slabs are in that order
+        const int n = (int)(idx - (size_t)mt * p.N);
+        const int m = out_row(p, mt);
         int img;
         const unsigned long long ro = row_offset(p, m, img);
         const float e[4] = {v.x, v.y, v.z, v.w};
