@@ -78,7 +78,7 @@ struct Workspace {
     void* base = nullptr;
     size_t bytes = 0;
     float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
-    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part, *zeros;
+    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part, *zeros, *stem_static;
     size_t stats_part_floats = 0;
     size_t partial_floats = 0;
     // sampler: device-resident loop state, per-timestep update coefficients, private copies of the inputs
@@ -395,6 +395,7 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
         ws.partial = bp.take(ws.partial_floats);
         ws.zeros = bp.take(64);
+        ws.stem_static = bp.take(B * hw2 * 64);
         if (!pass) {
             ws.bytes = bp.off;
             if (hipMalloc(&ws.base, ws.bytes) != hipSuccess) {
@@ -459,19 +460,35 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     return DANRA_OK;
 }
 
-int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B, int H, int W, const float* tbias,
-             hipStream_t st) {
+// The 8x8 stride-2 stem on input planes [first, first + count) of the concatenated input: a column slice of
+// the stem's weight matrix ([64][Cin*64], 64 columns per plane).  `res` (NHWC, 64 channels) is added to the result.
+int run_stem_planes(danra_handle_s* h, const float* const planes[4], int first, int count, float* out, int B, int H,
+                    int W, const float* res, const float* tbias, hipStream_t st) {
     IGemmArgs a = blank_args();
     const ConvP& c = h->stem;
-    for (int i = 0; i < 4; ++i) a.planes[i] = planes[i];
-    a.W = c.w; a.tbias = tbias; a.out = out;
-    a.M = B * (H / 2) * (W / 2); a.N = 64; a.K = 64 * c.Cin;
+    for (int i = 0; i < count; ++i) a.planes[i] = planes[first + i];
+    a.W = c.w + 64 * first; a.ldw = 64 * c.Cin; a.tbias = tbias; a.out = out;
+    a.res = res; a.ldr = 64;
+    a.M = B * (H / 2) * (W / 2); a.N = 64; a.K = 64 * count;
     a.a_mode = A_CONV1;
-    a.Hi = H; a.Wi = W; a.Cin = c.Cin; a.Ho = H / 2; a.Wo = W / 2; a.KH = 8; a.KW = 8; a.stride = 2; a.pad = 3;
+    a.Hi = H; a.Wi = W; a.Cin = count; a.Ho = H / 2; a.Wo = W / 2; a.KH = 8; a.KW = 8; a.stride = 2; a.pad = 3;
     a.tb_stride = h->tb_width; a.rows_per_img = (H / 2) * (W / 2);
     a.st_mode = ST_ROW; a.ldc = 64;
     HIP_TRY(launch_igemm(a, st));
     return DANRA_OK;
+}
+
+// Encoder.conv1 on cat([x, lsm, topo, cond]) (modules:228-238,260).  The convolution is linear in its input
+// planes, so it is evaluated as (conditioning planes) + (x plane): the first term does not change during a
+// sampling loop and is then computed once per danra_sample call (`static_ready`), leaving a K = 64 convolution
+// per denoise step.  Every caller uses the same two-term evaluation, so results do not depend on who calls.
+int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B, int H, int W, const float* tbias,
+             bool static_ready, hipStream_t st) {
+    const int Cin = h->stem.Cin;
+    if (Cin == 1) return run_stem_planes(h, planes, 0, 1, out, B, H, W, nullptr, tbias, st);
+    if (!static_ready)
+        RC_TRY(run_stem_planes(h, planes, 1, Cin - 1, h->ws.stem_static, B, H, W, nullptr, nullptr, st));
+    return run_stem_planes(h, planes, 0, 1, out, B, H, W, h->ws.stem_static, tbias, st);
 }
 
 int prof_mark(danra_handle_s* h, hipStream_t st) {
@@ -593,7 +610,7 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
 // `t` gives one timestep per image; with t == null every image uses the sampler state's current one.
 int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleState* state, const int64_t* y,
                  const float* cond, const float* lsm, const float* topo, float* eps, int B, int H, int W,
-                 hipStream_t st) {
+                 hipStream_t st, bool stem_static_ready = false) {
     Workspace& ws = h->ws;
     RC_TRY(run_time_mlp(h, t, state, y, B, nullptr, nullptr, ws.tbias, st));
     const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -602,7 +619,7 @@ int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleStat
     if (h->cfg.has_lsm) planes[np++] = lsm;
     if (h->cfg.has_topo) planes[np++] = topo;
     if (h->cfg.has_cond) planes[np++] = cond;
-    RC_TRY(run_stem(h, planes, ws.f1pre, B, H, W, ws.tbias + h->tb_off_enc[0], st));
+    RC_TRY(run_stem(h, planes, ws.f1pre, B, H, W, ws.tbias + h->tb_off_enc[0], stem_static_ready, st));
     int Hc = H / 2, Wc = W / 2;
     RC_TRY(run_attention(h, 0, ws.f1pre, ws.fmap[0], B, Hc * Wc, 0, st));
     RC_TRY(run_conv(h, h->conv2, ws.fmap[0], ws.c2, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st));
@@ -815,9 +832,19 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
                               noise_mode == DANRA_NOISE_HOST ? noise : nullptr, st));
     RC_TRY(upload_freq(h, st));
 
+    // the conditioning planes' share of the stem convolution is the same at every step
+    if (h->stem.Cin > 1) {
+        const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+        int np = 0;
+        planes[np++] = ws.xs;
+        if (h->cfg.has_lsm) planes[np++] = ws.lsms;
+        if (h->cfg.has_topo) planes[np++] = ws.topos;
+        if (h->cfg.has_cond) planes[np++] = ws.conds;
+        RC_TRY(run_stem_planes(h, planes, 1, np - 1, ws.stem_static, B, H, W, nullptr, nullptr, st));
+    }
     auto enqueue_step = [&](hipStream_t s) -> int {
         RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, has_y ? ws.ys : nullptr, ws.conds, ws.lsms, ws.topos, ws.eps, B,
-                            H, W, s));
+                            H, W, s, true));
         HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, ws.coef, ws.state, n, s));
         return DANRA_OK;
     };
@@ -924,7 +951,8 @@ int danra_conv1(danra_handle_t h, const float* x, const float* lsm, const float*
     if (h->cfg.has_cond) planes[np++] = cond;
     for (int i = 0; i < np; ++i)
         if (!planes[i]) return fail(DANRA_EINVAL, "missing input plane %d", i);
-    return run_stem(h, planes, out, B, H, W, nullptr, (hipStream_t)stream);
+    RC_TRY(op_workspace(h, B, (long)(H / 2) * (W / 2)));
+    return run_stem(h, planes, out, B, H, W, nullptr, false, (hipStream_t)stream);
 }
 
 int danra_conv2_bn_relu(danra_handle_t h, const float* x, float* out, int B, int H, int W, void* stream) {

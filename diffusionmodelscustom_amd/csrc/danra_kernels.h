@@ -31,6 +31,7 @@ struct IGemmArgs {
     float* partial;  // split-K slabs [ksplit][M][N]
     int M, N, K;
     int lda;
+    int ldw;  // row stride of W in floats; 0 = K
     int a_mode;
     int ln;
     int Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad;

@@ -206,8 +206,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
     }
     int wbase[BR];
+    const int ldw = p.ldw ? p.ldw : p.K;  // weight row stride (a column slice of a wider matrix has ldw > K)
 #pragma unroll
-    for (int j = 0; j < BR; ++j) wbase[j] = (n0 + lrow + SWEEP * j) * p.K + c4;
+    for (int j = 0; j < BR; ++j) wbase[j] = (n0 + lrow + SWEEP * j) * ldw + c4;
 
     // ---- LayerNorm statistics of this thread's rows (two-pass, fp32) over the whole K = channel
     //      count: TPR lanes share a row, same thread->row mapping as the staging loads
