@@ -591,9 +591,9 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
     HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
     RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
-    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st));
-    HIP_TRY(launch_in_apply(ws.cv, ws.mean2, ws.rstd2, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width, ws.pre, B,
-                            H2 * W2, d.Cout, st));
+    // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels)
+    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st, ws.pre,
+                            skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width));
     RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st));
     return DANRA_OK;
 }

@@ -87,8 +87,11 @@ struct TimeMlpArgs {
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
 
 // `part`: scratch of part_floats floats for sliced statistics (may be null: one block per image and 32 channels)
+// With `out` != null the normalised tensor (+ skip, + tbias[b][c]) is written as well (one fused pass when an
+// image's pixels fit a block's registers, statistics + k_in_apply otherwise).
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
-                           int C, hipStream_t stream);
+                           int C, hipStream_t stream, float* out = nullptr, const float* skip = nullptr,
+                           const float* tbias = nullptr, int tb_stride = 0);
 // out = (x - mean)*rstd [+ skip] [+ tbias[b][c]]
 hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip,
                            const float* tbias, int tb_stride, float* out, int B, int HW, int C, hipStream_t stream);

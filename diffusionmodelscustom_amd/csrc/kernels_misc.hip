@@ -183,10 +183,13 @@ __device__ __forceinline__ float4 block_sum_by_quad(float4 v, float4* red, int t
     return r;
 }
 
+// With `out` set (unsliced launches only) the block also applies the normalisation to the values it holds:
+// out = (x - mean) * rstd [+ skip] [+ tbias[image][channel]], the tail of a decoder block before its attention.
 template <int NP>
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
                                                   float* __restrict__ rstd, float* __restrict__ part, int HWtotal,
-                                                  int C) {
+                                                  int C, float* __restrict__ out, const float* __restrict__ skip,
+                                                  const float* __restrict__ tbias, int tb_stride) {
     __shared__ float4 red[32];
     const int b = blockIdx.x;
     const int c0 = blockIdx.y * 32;
@@ -231,6 +234,31 @@ __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, f
             *reinterpret_cast<float4*>(rstd + (size_t)b * C + c0 + cq) = r;
         }
     }
+    if (out && S == 1) {
+        float4 r, add = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.x = 1.0f / sqrtf(var.x * inv + 1e-5f);
+        r.y = 1.0f / sqrtf(var.y * inv + 1e-5f);
+        r.z = 1.0f / sqrtf(var.z * inv + 1e-5f);
+        r.w = 1.0f / sqrtf(var.w * inv + 1e-5f);
+        if (tbias) add = *reinterpret_cast<const float4*>(tbias + (size_t)b * tb_stride + c0 + cq);
+        const size_t base_off = (size_t)b * HWtotal * C + c0 + cq;
+        float4 sk[NP];
+        if (skip) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                sk[i] = *reinterpret_cast<const float4*>(skip + base_off + (size_t)min(slot + 32 * i, HW - 1) * C);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (slot + 32 * i >= HW) continue;
+            // same operation order as k_in_apply: normalise, + skip, + time bias
+            float4 o;
+            o.x = (v[i].x - mu.x) * r.x; o.y = (v[i].y - mu.y) * r.y; o.z = (v[i].z - mu.z) * r.z; o.w = (v[i].w - mu.w) * r.w;
+            if (skip) { o.x += sk[i].x; o.y += sk[i].y; o.z += sk[i].z; o.w += sk[i].w; }
+            o.x += add.x; o.y += add.y; o.z += add.z; o.w += add.w;
+            *reinterpret_cast<float4*>(out + base_off + (size_t)(slot + 32 * i) * C) = o;
+        }
+    }
 }
 
 __global__ void k_in_stats_merge(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
@@ -262,7 +290,7 @@ __global__ void k_in_stats_merge(const float* __restrict__ part, float* __restri
 }
 
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
-                           int C, hipStream_t stream) {
+                           int C, hipStream_t stream, float* out, const float* skip, const float* tbias, int tb_stride) {
     constexpr long min_blocks = 128;  // measured on MI355X: more slices than this cost more in the merge than they gain
     // a block holds at most 1024 pixels x 32 channels in registers; more slices only while the grid is
     // small and the slices stay equal and at least 64 pixels long
@@ -271,13 +299,18 @@ hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part
         S *= 2;
         if (S > 32) return hipErrorInvalidValue;
     }
-    while (part && S < 32 && (long)B * (C / 32) * S < min_blocks && HW % (2 * S) == 0 && HW / (2 * S) >= 64) S *= 2;
+    while (!out && part && S < 32 && (long)B * (C / 32) * S < min_blocks && HW % (2 * S) == 0 && HW / (2 * S) >= 64) S *= 2;
+    if (out && S > 1) {  // too many pixels to hold in one block's registers: statistics, then a separate apply pass
+        hipError_t e = launch_in_stats(x, mean, rstd, part, part_floats, B, HW, C, stream, nullptr, nullptr, nullptr, 0);
+        if (e != hipSuccess) return e;
+        return launch_in_apply(x, mean, rstd, skip, tbias, tb_stride, out, B, HW, C, stream);
+    }
     if (S > 1 && (!part || (size_t)B * S * 2 * C > part_floats)) return hipErrorInvalidValue;
     const int per = (HW / S + 31) / 32;
     const dim3 grid(B, C / 32, S);
-    if (per <= 2) hipLaunchKernelGGL(k_in_stats<2>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
-    else if (per <= 8) hipLaunchKernelGGL(k_in_stats<8>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
-    else hipLaunchKernelGGL(k_in_stats<32>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C);
+    if (per <= 2) hipLaunchKernelGGL(k_in_stats<2>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
+    else if (per <= 8) hipLaunchKernelGGL(k_in_stats<8>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
+    else hipLaunchKernelGGL(k_in_stats<32>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
     if (S > 1)
         hipLaunchKernelGGL(k_in_stats_merge, dim3((B * C + 255) / 256), dim3(256), 0, stream, part, mean, rstd, B * C, C, S,
                            HW / S);
