@@ -485,10 +485,15 @@ int run_stem_planes(danra_handle_s* h, const float* const planes[4], int first, 
 int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B, int H, int W, const float* tbias,
              bool static_ready, hipStream_t st) {
     const int Cin = h->stem.Cin;
-    if (Cin == 1) return run_stem_planes(h, planes, 0, 1, out, B, H, W, nullptr, tbias, st);
-    if (!static_ready)
-        RC_TRY(run_stem_planes(h, planes, 1, Cin - 1, h->ws.stem_static, B, H, W, nullptr, nullptr, st));
-    return run_stem_planes(h, planes, 0, 1, out, B, H, W, h->ws.stem_static, tbias, st);
+    const float* res = nullptr;
+    if (Cin > 1) {
+        if (!static_ready)
+            RC_TRY(run_stem_planes(h, planes, 1, Cin - 1, h->ws.stem_static, B, H, W, nullptr, nullptr, st));
+        res = h->ws.stem_static;
+    }
+    // the x plane: a dedicated kernel (H, W are multiples of 32 here)
+    HIP_TRY(launch_stem_x(planes[0], h->stem.w, 64 * Cin, res, tbias, h->tb_width, out, B, H, W, st));
+    return DANRA_OK;
 }
 
 int prof_mark(danra_handle_s* h, hipStream_t st) {

@@ -47,6 +47,11 @@ struct IGemmArgs {
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
 
+// One input plane's share of the 8x8 stride-2 pad-3 stem: out = conv(x; Wt[64][8x8], row stride ldw) [+ res] [+ tbias[b]],
+// x: [B][H][W], out/res: [B][H/2][W/2][64]; H and W multiples of 16.
+hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* res, const float* tbias, int tb_stride,
+                         float* out, int B, int H, int W, hipStream_t stream);
+
 // ---------------------------------------------------------------- attention
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads,

@@ -605,6 +605,95 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The x-plane share of the 8x8 stride-2 stem (one input plane, 64 output channels, K = 64 taps):
+//   out[b][oy][ox][n] = sum_{kh,kw} x[b][2oy-3+kh][2ox-3+kw] * W[n][kh*8+kw] + res[b][oy][ox][n] + tbias[b][n].
+// A workgroup owns an 8x8 patch of output pixels of one image.  Its 22x22 input window (zero padded) and the
+// 64x64 weight slice are staged in LDS once; the MFMA operand of a pixel is then read straight from the window
+// (lane (pixel, h) needs taps kw = 4h..4h+3 of kernel row u: four consecutive floats), so there is no
+// per-tap address arithmetic, bounds test or staging loop at all.  Same fragment convention as k_igemm.
+__global__ __launch_bounds__(256) void k_stem_x(const float* __restrict__ x, const float* __restrict__ Wt, int ldw,
+                                                const float* __restrict__ res, const float* __restrict__ tbias,
+                                                int tb_stride, float* __restrict__ out, int H, int W) {
+    constexpr int PW = 24;   // padded window row (floats)
+    constexpr int LDK = 68;
+    __shared__ __attribute__((aligned(16))) float win[22 * PW];
+    __shared__ __attribute__((aligned(16))) float Ws[64 * LDK];   // reused as the output tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = Wo / 8;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.y;
+    // ---- weights: 64 rows x 64 taps
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(Wt + (size_t)(r + 16 * j) * ldw + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(Ws + (r + 16 * j) * LDK + c4) = w[j];
+    }
+    // ---- input window: rows 16ty-3 .. 16ty+18, columns 16tx-3 .. 16tx+18
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = tid; i < 22 * 22; i += 256) {
+        const int r = i / 22, c = i - r * 22;
+        const int iy = 16 * ty - 3 + r, ix = 16 * tx - 3 + c;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float v = xb[ok ? iy * W + ix : 0];
+        win[r * PW + c] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = (lane >> 5) * 4;
+    const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 32;
+    const int pix = row0 + fr;                 // pixel of the 8x8 patch: (pix >> 3, pix & 7)
+    const float* ap = win + (2 * (pix >> 3)) * PW + 2 * (pix & 7) + fh;
+    const float* bp = Ws + (col0 + fr) * LDK + fh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // kernel row u: k = 8u + 4h + {0..3}
+        const float2 a01 = *reinterpret_cast<const float2*>(ap + u * PW);
+        const float2 a23 = *reinterpret_cast<const float2*>(ap + u * PW + 2);
+        const float4 bw = *reinterpret_cast<const float4*>(bp + u * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.x, a01.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.y, a01.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.z, a23.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.w, a23.y, acc, 0, 0, 0);
+    }
+    // ---- epilogue through LDS: acc[r] = out[pixel row0 + (lane & 31)][channel col0 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
+    __syncthreads();
+    float* tile = Ws;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(tile + pix * LDK + col0 + 8 * g + fh) =
+            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    __syncthreads();
+    const int oc4 = (tid & 15) * 4;
+    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tbias) tb = *reinterpret_cast<const float4*>(tbias + (size_t)b * tb_stride + oc4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = (tid >> 4) + 16 * j;
+        const size_t o = (((size_t)b * Ho + 8 * ty + (p >> 3)) * Wo + 8 * tx + (p & 7)) * 64 + oc4;
+        float4 v = *reinterpret_cast<const float4*>(tile + p * LDK + oc4);
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + o);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        v.x += tb.x; v.y += tb.y; v.z += tb.z; v.w += tb.w;
+        *reinterpret_cast<float4*>(out + o) = v;
+    }
+}
+
+hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* res, const float* tbias, int tb_stride,
+                         float* out, int B, int H, int W, hipStream_t stream) {
+    if (H % 16 || W % 16 || ldw % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stem_x, dim3((H / 16) * (W / 16), B), dim3(256), 0, stream, x, Wt, ldw, res, tbias, tb_stride, out,
+                       H, W);
+    return hipGetLastError();
+}
+
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     // every store mode keeps runs of four output columns contiguous when its inner extent is a multiple of 4
