@@ -126,6 +126,11 @@ struct danra_handle_s {
     int graph_mode = 1;
     hipStream_t cap_stream = nullptr;
     std::vector<float4> h_coef;
+    // time projections of every (timestep, class) pair, rebuilt by each danra_sample call
+    float* tb_table = nullptr;
+    int64_t* tb_index = nullptr;  // [2][rows]: the timestep and the class of every table row
+    size_t tb_rows_cap = 0;
+    std::vector<int64_t> h_tb_index;
 };
 
 namespace {
@@ -615,9 +620,13 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
 // `t` gives one timestep per image; with t == null every image uses the sampler state's current one.
 int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleState* state, const int64_t* y,
                  const float* cond, const float* lsm, const float* topo, float* eps, int B, int H, int W,
-                 hipStream_t st, bool stem_static_ready = false) {
+                 hipStream_t st, bool stem_static_ready = false, const float* tb_table = nullptr) {
     Workspace& ws = h->ws;
-    RC_TRY(run_time_mlp(h, t, state, y, B, nullptr, nullptr, ws.tbias, st));
+    if (tb_table)  // sampling loop: the projections were tabulated for every timestep before the loop
+        HIP_TRY(launch_tbias_gather(state, tb_table, y, ws.tbias, h->cfg.num_classes > 0 && y ? h->cfg.num_classes : 1,
+                                    h->tb_width, B, st));
+    else
+        RC_TRY(run_time_mlp(h, t, state, y, B, nullptr, nullptr, ws.tbias, st));
     const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
     int np = 0;
     planes[np++] = x;
@@ -698,6 +707,8 @@ int danra_destroy(danra_handle_t h) {
     drop_step_graph(h->ws);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->tb_table) (void)hipFree(h->tb_table);
+    if (h->tb_index) (void)hipFree(h->tb_index);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     delete h;
     return DANRA_OK;
@@ -837,6 +848,30 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
                               noise_mode == DANRA_NOISE_HOST ? noise : nullptr, st));
     RC_TRY(upload_freq(h, st));
 
+    // the time projections of every (timestep, class) pair, tabulated once: [T][classes][width]
+    const int classes = has_y ? h->cfg.num_classes : 1;
+    {
+        const size_t rows = (size_t)T * classes;
+        if (rows > h->tb_rows_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h->tb_table) (void)hipFree(h->tb_table);
+            if (h->tb_index) (void)hipFree(h->tb_index);
+            h->tb_table = nullptr; h->tb_index = nullptr; h->tb_rows_cap = 0;
+            drop_step_graph(ws);  // the captured step refers to the table
+            if (hipMalloc((void**)&h->tb_table, rows * h->tb_width * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&h->tb_index, 2 * rows * sizeof(int64_t)) != hipSuccess)
+                return fail(DANRA_ENOMEM, "time-projection table of %zu rows: allocation failed", rows);
+            h->tb_rows_cap = rows;
+        }
+        h->h_tb_index.resize(2 * rows);
+        for (size_t r = 0; r < rows; ++r) {
+            h->h_tb_index[r] = (int64_t)(r / classes);
+            h->h_tb_index[rows + r] = (int64_t)(r % classes);
+        }
+        HIP_TRY(hipMemcpyAsync(h->tb_index, h->h_tb_index.data(), 2 * rows * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        RC_TRY(run_time_mlp(h, h->tb_index, nullptr, has_y ? h->tb_index + rows : nullptr, (int)rows, nullptr, nullptr,
+                            h->tb_table, st));
+    }
     // the conditioning planes' share of the stem convolution is the same at every step
     if (h->stem.Cin > 1) {
         const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -849,7 +884,7 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
     }
     auto enqueue_step = [&](hipStream_t s) -> int {
         RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, has_y ? ws.ys : nullptr, ws.conds, ws.lsms, ws.topos, ws.eps, B,
-                            H, W, s, true));
+                            H, W, s, true, h->tb_table));
         HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, ws.coef, ws.state, n, s));
         return DANRA_OK;
     };

@@ -90,6 +90,9 @@ struct TimeMlpArgs {
     int B, dim, width, enc_width, num_classes;
 };
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
+// tbias[b] = table[state->t_fwd][y_b] (table: [T][classes][width]); also publishes state->t_upd = state->t_fwd
+hipError_t launch_tbias_gather(SampleState* state, const float* table, const int64_t* y, float* tbias, int classes,
+                               int width, int B, hipStream_t stream);
 
 // `part`: scratch of part_floats floats for sliced statistics (may be null: one block per image and 32 channels)
 // With `out` != null the normalised tensor (+ skip, + tbias[b][c]) is written as well (one fused pass when an

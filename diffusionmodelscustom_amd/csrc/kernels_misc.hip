@@ -158,6 +158,34 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sampling loop: the time projections of every (timestep, label class) pair are tabulated once per sampling
+// call ([T][classes][width], by k_time_mlp); a denoise step then only gathers its rows:
+// tbias[b] = table[t][y_b] with t read from the device-resident loop state (which this kernel also publishes
+// for the update kernel, as k_time_mlp does).
+__global__ __launch_bounds__(256) void k_tbias_gather(SampleState* state, const float* __restrict__ table,
+                                                      const int64_t* __restrict__ y, float* __restrict__ tbias,
+                                                      int classes, int width, int B) {
+    const int t = state->t_fwd;
+    if (blockIdx.x == 0 && threadIdx.x == 0) state->t_upd = t;
+    const int w4 = width / 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * w4; i += gridDim.x * blockDim.x) {
+        const int b = i / w4, j = i - b * w4;
+        const int c = y ? (int)y[b] : 0;
+        reinterpret_cast<float4*>(tbias)[i] =
+            reinterpret_cast<const float4*>(table + ((size_t)t * classes + c) * width)[j];
+    }
+}
+
+hipError_t launch_tbias_gather(SampleState* state, const float* table, const int64_t* y, float* tbias, int classes,
+                               int width, int B, hipStream_t stream) {
+    if (width % 4) return hipErrorInvalidValue;
+    int blocks = (B * (width / 4) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_tbias_gather, dim3(blocks), dim3(256), 0, stream, state, table, y, tbias, classes, width, B);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // InstanceNorm statistics on NHWC: block = (image, 32 channels[, pixel slice]); 8 channel quads x 32 pixel
 // slots, NP pixels per thread.  The block's pixels are read ONCE into registers (every load in flight
 // together); the mean and then the centred sum of squares are formed from the registers, so the biased
