@@ -216,7 +216,8 @@ def main():
             "whole_path_tflops": value * (T - 1) * fl_img / 1e12 / world,
             "whole_path_frac_of_fp32_peak": value * (T - 1) * fl_img / 1e12 / world / FP32_MATRIX_PEAK_TFLOPS,
             "roofline": {
-                "kernel": "k_flash_hd16 (head_dim-16 flash attention: every launch of the timed region, HIP events)",
+                "kernel": "k_flash_hd16 (head_dim-16 flash attention: HIP events around its launches in every 8th denoise "
+                          "step of the timed region)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP32_MATRIX_PEAK_TFLOPS,

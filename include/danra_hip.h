@@ -129,13 +129,15 @@ int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alp
 /* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
  * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns
  * it off), 0 enqueues every kernel of every step.  Both modes run the same kernels on the same data and
- * give bit-identical results.  While a danra_profile_begin measurement is active the loop is enqueued. */
+ * give bit-identical results. */
 int danra_set_graph_mode(danra_handle_t h, int enable);
 
 /* Measurement hook (no counterpart in the reference, which holds no timing code): between _begin and
  * _end every launch of the named kernel family is bracketed by HIP events on the stream it is launched
  * on.  _end waits for the last event (host sync) and returns the summed kernel time, the number of
- * launches and their algorithmic FLOPs (2 per multiply-add of QK^T and PV). */
+ * launches and their algorithmic FLOPs (2 per multiply-add of QK^T and PV).  danra_unet_forward times every
+ * launch; danra_sample times the launches of every 8th denoise step (that step is enqueued kernel by kernel, the
+ * others are replayed from the graph as usual), so that the event records do not slow the loop being measured. */
 #define DANRA_PROF_FLASH_ATTENTION 1 /* the head_dim-16 flash attention kernel */
 int danra_profile_begin(danra_handle_t h, int kind);
 int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, double* total_flops);
