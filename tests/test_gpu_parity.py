@@ -394,3 +394,34 @@ def test_noise_image_bit_exact_and_philox(golden, dev, sched):
     keep = torch.sqrt(du.alpha_hat[tb])[:, None, None, None]
     spread = torch.sqrt(1 - du.alpha_hat[tb])[:, None, None, None]
     assert torch.equal(n1, (keep * xb) + (spread * z1))
+
+
+def test_sampler_state_is_rebuilt_between_calls(cond64, dev):
+    """Per-call sampler state (coefficient table, time-projection table, captured step) follows a change of T and of
+    the label argument: every call equals the kernel-by-kernel loop and a repeat of itself."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, _ = cond64
+    engine = model.hip_engine(dev)
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 2, 64, seed=31).items()}
+    results = {}
+    try:
+        for graph in (True, False):
+            engine.set_graph_mode(graph)
+            outs = []
+            for T, use_y in ((6, True), (9, True), (9, False), (6, True), (1500, True)):
+                du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+                steps = 4 if T > 100 else T  # a long table, only its last few timesteps walked
+                if T > 100:
+                    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "cosine")
+                    betas, alphas, ah = du.betas[:steps].clone(), du.alphas[:steps].clone(), du.alpha_hat[:steps].clone()
+                else:
+                    betas, alphas, ah = du.betas, du.alphas, du.alpha_hat
+                outs.append(engine.sample(inp["x"].clone(), inp["y"] if use_y else None, inp["cond_img"], inp["lsm_cond"],
+                                          inp["topo_cond"], betas, alphas, ah, seed=3))
+            results[graph] = outs
+    finally:
+        engine.set_graph_mode(True)
+    for a, b in zip(results[True], results[False]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(results[True][0], results[True][3])          # same arguments, same result
+    assert not torch.equal(results[True][1], results[True][2])      # the label embedding matters
