@@ -13,7 +13,10 @@ def main():
     brief = "--brief" in sys.argv
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "k_time_mlp" in r["Kernel_Name"]]
+    # first kernel of a UNet evaluation: the per-step gather inside the sampler, else the time-projection kernel
+    marks = [i for i, r in enumerate(rows) if "k_tbias_gather" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        marks = [i for i, r in enumerate(rows) if "k_time_mlp" in r["Kernel_Name"]]
     a, b = marks[-2], marks[-1]
     tot = 0.0
     per = defaultdict(lambda: [0, 0.0])
