@@ -425,3 +425,21 @@ def test_sampler_state_is_rebuilt_between_calls(cond64, dev):
         assert torch.equal(a, b) and torch.isfinite(a).all()
     assert torch.equal(results[True][0], results[True][3])          # same arguments, same result
     assert not torch.equal(results[True][1], results[True][2])      # the label embedding matters
+
+
+def test_c1_unconditional_32x32_T200_chain(dev):
+    """BASELINE config C1 (the reference's own CPU-runnable case restated: unconditional 1x32x32, T=200, B=4,
+    linear betas): the whole sampling call on the GPU against the CPU restatement with the same host noise, and
+    the cosine schedule on the same model."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model = build_model("uncond", 32).to(dev).eval()
+    sd = state_dict_cpu(model)
+    x0 = gs.randn(55, 4, 1, 32, 32)
+    for sched, T in (("linear", 200), ("cosine", 60)):
+        du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, sched)
+        fn = gs.chain_noise_fn(gs.SEED + 3)
+        noise = torch.stack([fn(i, x0) for i in range(T - 1, 1, -1)])
+        fn = gs.chain_noise_fn(gs.SEED + 3)
+        want = cpu_ref.sample(sd, x0.clone(), T, gs.BETA_MIN, gs.BETA_MAX, scheduler=sched, noise_fn=fn)
+        got = du.sample_with_host_noise(x0.to(dev), model, noise.to(dev))
+        assert rel_err(got.cpu(), want) < TOL_CHAIN, sched
