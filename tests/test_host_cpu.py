@@ -155,3 +155,34 @@ def test_noise_image_cpu_path_matches_golden(golden):
     assert torch.equal(noisy2, noisy) and noise2 is noise
     with pytest.raises(AssertionError, match="x must be a 4D tensor"):
         du.noiseImage(x[0], t)
+
+
+def test_checkpoint_round_trip_and_training_step(tmp_path):
+    """The reference's checkpoint format and training step on top of these modules (next rows f1/f3):
+    torch.save({'network_params', 'optimizer_params'}) as training_DANRA_conditional.py:755-772 writes it, strict
+    load into a fresh model, one AdamW step on the noise-prediction loss (training:963-984) that changes the weights."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model = build_model("cond", 32)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    path = tmp_path / "ckpt.pth.tar"
+    torch.save({"network_params": model.state_dict(), "optimizer_params": opt.state_dict()}, path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    fresh = build_model("cond", 32, seed=gs.SEED + 1)
+    fresh.load_state_dict(ckpt["network_params"])  # strict
+    inp = gs.variant_inputs("cond", 2, 32)
+    t = torch.tensor([3, 40])
+    with torch.no_grad():
+        a = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        b = fresh(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+    assert torch.equal(a, b)
+    du = DiffusionUtils(100, gs.BETA_MIN, gs.BETA_MAX, "cpu", "linear")
+    model.train()
+    tt = du.sampleTimesteps(2)
+    assert tt.min() >= 1 and tt.max() < 100
+    noisy, noise = du.noiseImage(inp["x"], tt)
+    before = model.decoder.final_layer.conv.weight.detach().clone()
+    loss = torch.nn.functional.mse_loss(model(noisy, tt, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]), noise)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss) and not torch.equal(before, model.decoder.final_layer.conv.weight)
