@@ -9,7 +9,7 @@
 // k_attn_reg: the deeper levels (L <= 256 tokens, head_dim 32 / 64 / 128): one wave per 16-query tile, all
 // score tiles in registers, exact two-pass softmax, operands read straight from memory.
 //
-// k_attn_small: fallback for any other shape (one wave per query row, K/V of the (image, head) pair in LDS).
+// k_attn_small: fallback for any other shape (plain VALU, keys walked in LDS chunks with online softmax).
 #include "danra_kernels.h"
 
 namespace danra {
@@ -319,61 +319,86 @@ static hipError_t launch_attn_reg(const float* q, const float* k, const float* v
     return hipGetLastError();
 }
 
-// Generic small-shape attention: grid (B*heads, query blocks); K (padded rows) and V in LDS.
+// Generic fallback for any other shape (any L, head_dim <= 128): grid (B*heads, ceil(L/32)); a workgroup owns 32
+// queries (8 per wave, their running maximum / sum / output in registers) and walks the keys in chunks of 64
+// staged in LDS, with the usual online-softmax rescaling between chunks.  Plain VALU arithmetic: correctness
+// first, this path is not on any benchmarked configuration.
+constexpr int AS_KC = 64;   // keys per chunk
+constexpr int AS_QPW = 8;   // queries per wave
 __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O, int L,
-                                                    int hd, int heads, int q_per_block, float scale) {
+                                                    int hd, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int kst = hd + 1;
-    float* Ks = sm;                        // [L][hd+1]
-    float* Vs = Ks + (size_t)L * kst;      // [L][hd]
-    float* Ps = Vs + (size_t)L * hd;       // [4 waves][L]
-    float* Qs = Ps + 4 * L;                // [4 waves][hd]
+    float* Ks = sm;                          // [AS_KC][hd+1]
+    float* Vs = Ks + AS_KC * kst;            // [AS_KC][hd]
+    float* Ps = Vs + AS_KC * hd;             // [4 waves][AS_KC]
+    float* Qs = Ps + 4 * AS_KC;              // [4 waves][AS_QPW][hd]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x;
     const float* Qb = Q + (size_t)bh * L * hd;
     const float* Kb = K + (size_t)bh * L * hd;
     const float* Vb = V + (size_t)bh * L * hd;
-    for (int i = tid; i < L * hd; i += 256) {
-        const int r = i / hd, c = i - r * hd;
-        Ks[r * kst + c] = Kb[i];
-        Vs[i] = Vb[i];
+    const int q0 = blockIdx.y * (4 * AS_QPW) + wave * AS_QPW;
+    float* Pw = Ps + wave * AS_KC;
+    float* Qw = Qs + wave * AS_QPW * hd;
+    for (int i = lane; i < AS_QPW * hd; i += 64) {
+        const int qi = i / hd, d = i - qi * hd;
+        Qw[i] = Qb[(size_t)min(q0 + qi, L - 1) * hd + d] * scale;
     }
-    __syncthreads();
+    float m[AS_QPW], l[AS_QPW], o0[AS_QPW], o1[AS_QPW];  // lane holds output columns lane and lane + 64
+#pragma unroll
+    for (int qi = 0; qi < AS_QPW; ++qi) { m[qi] = -INFINITY; l[qi] = 0.f; o0[qi] = 0.f; o1[qi] = 0.f; }
+    for (int k0 = 0; k0 < L; k0 += AS_KC) {
+        const int nk = min(AS_KC, L - k0);
+        __syncthreads();  // the previous chunk has been consumed (and Qw is written, the first time round)
+        for (int i = tid; i < nk * hd; i += 256) {
+            const int r = i / hd, c = i - r * hd;
+            Ks[r * kst + c] = Kb[(size_t)k0 * hd + i];
+            Vs[i] = Vb[(size_t)k0 * hd + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < AS_QPW; ++qi) {
+            float sc = -INFINITY;
+            if (lane < nk) {
+                sc = 0.f;
+                for (int d = 0; d < hd; ++d) sc = fmaf(Qw[qi * hd + d], Ks[lane * kst + d], sc);
+            }
+            float cm = sc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cm = fmaxf(cm, __shfl_xor(cm, off));
+            const float mn = fmaxf(m[qi], cm);
+            const float alpha = expf(m[qi] - mn);  // 0 the first time round (m = -inf)
+            const float pe = (lane < nk) ? expf(sc - mn) : 0.f;
+            float ps = pe;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+            l[qi] = l[qi] * alpha + ps;
+            m[qi] = mn;
+            Pw[lane] = pe;
+            __builtin_amdgcn_wave_barrier();
+            float a0 = 0.f, a1 = 0.f;
+            for (int j = 0; j < nk; ++j) {
+                const float pj = Pw[j];
+                if (lane < hd) a0 = fmaf(pj, Vs[j * hd + lane], a0);
+                if (lane + 64 < hd) a1 = fmaf(pj, Vs[j * hd + lane + 64], a1);
+            }
+            o0[qi] = o0[qi] * alpha + a0;
+            o1[qi] = o1[qi] * alpha + a1;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     const int b = bh / heads, head = bh - b * heads;
     const int C = heads * hd;
-    const int qbeg = blockIdx.y * q_per_block;
-    const int qend = min(L, qbeg + q_per_block);
-    float* Pw = Ps + wave * L;
-    float* Qw = Qs + wave * hd;
-    for (int q = qbeg + wave; q < qend; q += 4) {
-        for (int d = lane; d < hd; d += 64) Qw[d] = Qb[(size_t)q * hd + d] * scale;
-        __builtin_amdgcn_wave_barrier();
-        float mx = -INFINITY;
-        for (int j = lane; j < L; j += 64) {
-            float sacc = 0.f;
-            for (int d = 0; d < hd; ++d) sacc = fmaf(Qw[d], Ks[j * kst + d], sacc);
-            Pw[j] = sacc;
-            mx = fmaxf(mx, sacc);
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-        for (int j = lane; j < L; j += 64) {
-            const float e = expf(Pw[j] - mx);
-            Pw[j] = e;
-            sum += e;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.0f / sum;
-        __builtin_amdgcn_wave_barrier();
-        for (int d = lane; d < hd; d += 64) {
-            float oacc = 0.f;
-            for (int j = 0; j < L; ++j) oacc = fmaf(Pw[j], Vs[j * hd + d], oacc);
-            O[((size_t)b * L + q) * C + head * hd + d] = oacc * inv;
-        }
-        __builtin_amdgcn_wave_barrier();
+    for (int qi = 0; qi < AS_QPW; ++qi) {
+        const int q = q0 + qi;
+        if (q >= L) continue;
+        const float inv = 1.0f / l[qi];
+        float* dst = O + ((size_t)b * L + q) * C + head * hd;
+        if (lane < hd) dst[lane] = o0[qi] * inv;
+        if (lane + 64 < hd) dst[lane + 64] = o1[qi] * inv;
     }
 }
 
@@ -390,19 +415,16 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
         if (hd == 64) return launch_attn_reg<4>(q, k, v, out, B, heads, L, stream);
         if (hd == 128) return launch_attn_reg<8>(q, k, v, out, B, heads, L, stream);
     }
-    const size_t lds = ((size_t)L * (hd + 1) + (size_t)L * hd + 4 * (size_t)L + 4 * (size_t)hd) * sizeof(float);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (hd > 128) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)AS_KC * (hd + 1) + (size_t)AS_KC * hd + 4 * AS_KC + 4 * AS_QPW * (size_t)hd) * sizeof(float);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_small),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int qblocks = 1;
-    while (B * heads * qblocks < 1024 && L / (qblocks * 2) >= 8) qblocks *= 2;
-    const int qpb = (L + qblocks - 1) / qblocks;
-    dim3 grid(B * heads, qblocks);
+    dim3 grid(B * heads, (L + 4 * AS_QPW - 1) / (4 * AS_QPW));
     const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(k_attn_small, grid, dim3(256), lds, stream, q, k, v, out, L, hd, heads, qpb, scale);
+    hipLaunchKernelGGL(k_attn_small, grid, dim3(256), lds, stream, q, k, v, out, L, hd, heads, scale);
     return hipGetLastError();
 }
 

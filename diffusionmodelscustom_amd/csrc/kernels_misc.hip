@@ -295,23 +295,30 @@ __global__ void k_in_stats_merge(const float* __restrict__ part, float* __restri
     if (i >= BC) return;
     const int b = i / C, c = i - b * C;
     const float* src = part + (size_t)b * S * 2 * C + c;
-    // S is a power of two <= 32; slices are loaded eight at a time so that the loads overlap
-    float ms[32], qs[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const int sc = min(s, S - 1);
-        ms[s] = src[(size_t)sc * 2 * C];
-        qs[s] = src[(size_t)sc * 2 * C + C];
-    }
+    // equal slice sizes: the mean is the mean of the slice means; the centred sums of squares add up with the
+    // between-slice term (Chan et al.).  Eight slices per step so that the loads overlap.
     float msum = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float v[8];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) msum += (s < S) ? ms[s] : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(s0 + u, S - 1) * 2 * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) msum += (s0 + u < S) ? v[u] : 0.f;
+    }
     const float mu = msum / (float)S;
     float m2 = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float v[8], q[8];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const float d = ms[s] - mu;
-        m2 += (s < S) ? qs[s] + (float)HWslice * d * d : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            v[u] = src[(size_t)min(s0 + u, S - 1) * 2 * C];
+            q[u] = src[(size_t)min(s0 + u, S - 1) * 2 * C + C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float d = v[u] - mu;
+            m2 += (s0 + u < S) ? q[u] + (float)HWslice * d * d : 0.f;
+        }
     }
     mean[i] = mu;
     rstd[i] = 1.0f / sqrtf(m2 / ((float)S * (float)HWslice) + 1e-5f);
@@ -325,7 +332,7 @@ hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part
     int S = 1;
     while (HW / S > 1024 || HW % S) {
         S *= 2;
-        if (S > 32) return hipErrorInvalidValue;
+        if (S > 4096) return hipErrorInvalidValue;
     }
     while (!out && part && S < 32 && (long)B * (C / 32) * S < min_blocks && HW % (2 * S) == 0 && HW / (2 * S) >= 64) S *= 2;
     if (out && S > 1) {  // too many pixels to hold in one block's registers: statistics, then a separate apply pass

@@ -443,3 +443,33 @@ def test_c1_unconditional_32x32_T200_chain(dev):
         want = cpu_ref.sample(sd, x0.clone(), T, gs.BETA_MIN, gs.BETA_MAX, scheduler=sched, noise_fn=fn)
         got = du.sample_with_host_noise(x0.to(dev), model, noise.to(dev))
         assert rel_err(got.cpu(), want) < TOL_CHAIN, sched
+
+
+def test_attention_fallback_shapes(cond64, dev):
+    """Shapes beyond the specialised kernels (a 256x256 image reaches L = 1024 at head_dim 32, L = 320 is not a multiple
+    of 128 at head_dim 16, L = 272 at head_dim 128 has a ragged last key chunk) take the generic online-softmax kernel."""
+    _, sd, ops = cond64
+    for seed, idx, name, shape in ((11, 2, "encoder.attention_layers.2", (1, 128, 32, 32)),
+                                   (12, 1, "encoder.attention_layers.1", (2, 64, 16, 20)),
+                                   (13, 4, "encoder.attention_layers.4", (1, 512, 16, 17))):
+        x = gs.randn(seed, *shape)
+        want = cpu_ref.image_self_attention(sd, name, x)
+        assert rel_err(ops.attention(idx, x.to(dev)).cpu(), want) < TOL_OP, name
+
+
+@pytest.mark.parametrize("size,batch", [((256, 256), 1), ((96, 160), 3)])
+def test_large_and_odd_images_against_the_torch_composition(dev, size, batch):
+    """Sizes beyond the golden fixtures: the HIP path against this package's differentiable torch-op composition
+    (itself pinned to the reference by the CPU tests) evaluated on the same GPU."""
+    H, W = size
+    model = build_model("cond", 64).to(dev).eval()   # the lsm/topo buffers' size is not used by forward
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(batch, 1, H, W, generator=g).to(dev)
+    planes = [torch.randn(batch, 1, H, W, generator=g).to(dev) for _ in range(3)]
+    y = torch.randint(0, 4, (batch,), generator=g).to(dev)
+    t = torch.randint(1, 1000, (batch,), generator=g).to(dev)
+    with torch.no_grad():
+        got = model(x, t, y, planes[0], planes[1], planes[2])
+    with torch.enable_grad():
+        want = model(x, t, y, planes[0], planes[1], planes[2]).detach()
+    assert rel_err(got.cpu(), want.cpu()) < TOL_FWD
