@@ -473,3 +473,17 @@ def test_large_and_odd_images_against_the_torch_composition(dev, size, batch):
     with torch.enable_grad():
         want = model(x, t, y, planes[0], planes[1], planes[2]).detach()
     assert rel_err(got.cpu(), want.cpu()) < TOL_FWD
+
+
+def test_batch_larger_than_the_benchmark(cond64, dev):
+    """B = 130 at 64x64 (twice the benchmark batch, not a multiple of anything): images equal their B = 1 evaluation."""
+    model, _, _ = cond64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 130, 64, seed=23).items()}
+    t = (torch.arange(130, device=dev) * 7) % 999 + 1
+    with torch.no_grad():
+        full = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert torch.isfinite(full).all()
+        for i in (0, 64, 129):
+            one = model(inp["x"][i:i + 1], t[i:i + 1], inp["y"][i:i + 1], inp["cond_img"][i:i + 1],
+                        inp["lsm_cond"][i:i + 1], inp["topo_cond"][i:i + 1])
+            assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
