@@ -58,6 +58,8 @@ struct AttnP {
     float* b_in = nullptr;   // [3C],    LayerNorm shift folded in
     float* w_out = nullptr;  // [C][C]
     float* b_out = nullptr;
+    // feed-forward block of the clean-application network (src/unet.py:91-96): LayerNorm folded into the first Linear
+    float *w_ff1 = nullptr, *b_ff1 = nullptr, *w_ff2 = nullptr, *b_ff2 = nullptr;
     int C = 0;
 };
 struct BlockP {
@@ -78,7 +80,7 @@ struct Workspace {
     void* base = nullptr;
     size_t bytes = 0;
     float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
-    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *stats_part, *zeros, *stem_static;
+    float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *eps_uncond, *stats_part, *zeros, *stem_static;
     size_t stats_part_floats = 0;
     size_t partial_floats = 0;
     // sampler: device-resident loop state, per-timestep update coefficients, private copies of the inputs
@@ -89,7 +91,7 @@ struct Workspace {
     int64_t* ys;
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
-    int step_exec_has_y = -1;
+    int step_exec_mode = -1;  // what the captured step was built for: bit 0 = labels, bit 1 = guided (two evaluations)
 };
 constexpr int kMaxTimesteps = 8192;  // rows of the coefficient table
 
@@ -131,6 +133,8 @@ struct danra_handle_s {
     float* tb_table = nullptr;
     int64_t* tb_index = nullptr;  // [2][rows]: the timestep and the class of every table row
     size_t tb_rows_cap = 0;
+    float* tb_table_u = nullptr;  // label-free rows [T][width] for the unconditional evaluations of a guided loop
+    size_t tb_u_cap = 0;
     std::vector<int64_t> h_tb_index;
 };
 
@@ -146,13 +150,32 @@ void add_bn(danra_handle_s* h, const std::string& p, int C) {
     add_param(h, p + ".running_mean", C);
     add_param(h, p + ".running_var", C);
 }
+// The MultiheadAttention module is `.attention` in modules_DANRA_conditional.py:87 and `.mha` in
+// DDPM_clean_application/src/unet.py:87, which also adds the `.ff` Sequential (:91-96).
+const char* mha_name(const danra_handle_s* h) { return h->cfg.attn_ff ? ".mha" : ".attention"; }
 void add_attn(danra_handle_s* h, const std::string& p, int C) {
+    const std::string m = p + mha_name(h);
+    if (h->cfg.attn_ff) {
+        add_param(h, m + ".in_proj_weight", (size_t)3 * C * C);
+        add_param(h, m + ".in_proj_bias", (size_t)3 * C);
+        add_param(h, m + ".out_proj.weight", (size_t)C * C);
+        add_param(h, m + ".out_proj.bias", C);
+        add_param(h, p + ".layernorm.weight", C);
+        add_param(h, p + ".layernorm.bias", C);
+        add_param(h, p + ".ff.0.weight", C);
+        add_param(h, p + ".ff.0.bias", C);
+        add_param(h, p + ".ff.1.weight", (size_t)C * C);
+        add_param(h, p + ".ff.1.bias", C);
+        add_param(h, p + ".ff.3.weight", (size_t)C * C);
+        add_param(h, p + ".ff.3.bias", C);
+        return;
+    }
     add_param(h, p + ".layernorm.weight", C);
     add_param(h, p + ".layernorm.bias", C);
-    add_param(h, p + ".attention.in_proj_weight", (size_t)3 * C * C);
-    add_param(h, p + ".attention.in_proj_bias", (size_t)3 * C);
-    add_param(h, p + ".attention.out_proj.weight", (size_t)C * C);
-    add_param(h, p + ".attention.out_proj.bias", C);
+    add_param(h, m + ".in_proj_weight", (size_t)3 * C * C);
+    add_param(h, m + ".in_proj_bias", (size_t)3 * C);
+    add_param(h, m + ".out_proj.weight", (size_t)C * C);
+    add_param(h, m + ".out_proj.bias", C);
 }
 
 void build_param_table(danra_handle_s* h) {
@@ -239,14 +262,29 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
         a.b_in = bp.take((size_t)3 * C);
         a.w_out = bp.take((size_t)C * C);
         a.b_out = bp.take(C);
+        if (h->cfg.attn_ff) {
+            a.w_ff1 = bp.take((size_t)C * C);
+            a.b_ff1 = bp.take(C);
+            a.w_ff2 = bp.take((size_t)C * C);
+            a.b_ff2 = bp.take(C);
+        }
         if (fill) {
-            HIP_TRY(launch_pack_inproj(src_of(h, p + ".attention.in_proj_weight"), src_of(h, p + ".attention.in_proj_bias"),
+            const std::string m = p + mha_name(h);
+            HIP_TRY(launch_pack_inproj(src_of(h, m + ".in_proj_weight"), src_of(h, m + ".in_proj_bias"),
                                        src_of(h, p + ".layernorm.weight"), src_of(h, p + ".layernorm.bias"), a.w_in,
-                                       a.b_in, C, st));
-            HIP_TRY(hipMemcpyAsync(a.w_out, src_of(h, p + ".attention.out_proj.weight"), (size_t)C * C * 4,
+                                       a.b_in, 3 * C, C, st));
+            HIP_TRY(hipMemcpyAsync(a.w_out, src_of(h, m + ".out_proj.weight"), (size_t)C * C * 4,
                                    hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(a.b_out, src_of(h, p + ".attention.out_proj.bias"), (size_t)C * 4,
+            HIP_TRY(hipMemcpyAsync(a.b_out, src_of(h, m + ".out_proj.bias"), (size_t)C * 4,
                                    hipMemcpyDeviceToDevice, st));
+            if (h->cfg.attn_ff) {
+                HIP_TRY(launch_pack_inproj(src_of(h, p + ".ff.1.weight"), src_of(h, p + ".ff.1.bias"),
+                                           src_of(h, p + ".ff.0.weight"), src_of(h, p + ".ff.0.bias"), a.w_ff1, a.b_ff1, C,
+                                           C, st));
+                HIP_TRY(hipMemcpyAsync(a.w_ff2, src_of(h, p + ".ff.3.weight"), (size_t)C * C * 4,
+                                       hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(a.b_ff2, src_of(h, p + ".ff.3.bias"), (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+            }
         }
         return DANRA_OK;
     };
@@ -352,7 +390,7 @@ void drop_step_graph(Workspace& ws) {
     if (ws.step_graph) (void)hipGraphDestroy(ws.step_graph);
     ws.step_exec = nullptr;
     ws.step_graph = nullptr;
-    ws.step_exec_has_y = -1;
+    ws.step_exec_mode = -1;
 }
 
 int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
@@ -396,6 +434,7 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         ws.mean2 = bp.take((size_t)B * 512);
         ws.rstd2 = bp.take((size_t)B * 512);
         ws.eps = bp.take((size_t)B * H * W * h->cfg.out_channels);
+        ws.eps_uncond = bp.take((size_t)B * H * W * h->cfg.out_channels);
         ws.stats_part_floats = (size_t)1 << 19;
         ws.stats_part = bp.take(ws.stats_part_floats);
         ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
@@ -455,7 +494,7 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     a.M = B * Ho * Wo; a.N = c.Cout; a.K = c.KH * c.KW * c.Cin;
     a.a_mode = A_CONV;
     a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
-    a.ldr = c.Cout; a.relu = relu; a.tb_stride = h->tb_width; a.rows_per_img = Ho * Wo;
+    a.ldr = c.Cout; a.act = relu ? ACT_RELU : ACT_NONE; a.tb_stride = h->tb_width; a.rows_per_img = Ho * Wo;
     a.st_mode = ST_ROW; a.ldc = c.Cout;
     // tiny maps: pixel-major rows, so that a tile's rows share their valid taps and the padding taps are skipped
     a.pix_major = (c.KH > 1 && Ho * Wo <= 64) ? 1 : 0;
@@ -532,12 +571,29 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         RC_TRY(prof_mark(h, st));
         h->prof_flops += 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
     }
+    // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
+    // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
+    const bool ff = at.w_ff1 != nullptr;
+    float* attended = ff ? ws.qkv : out;
     IGemmArgs o = blank_args();
     o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;
-    o.W = at.w_out; o.bias = at.b_out; o.res = x; o.ldr = C; o.relu = relu; o.out = out;
+    o.W = at.w_out; o.bias = at.b_out; o.res = x; o.ldr = C; o.act = (relu && !ff) ? ACT_RELU : ACT_NONE; o.out = attended;
     o.M = B * L; o.N = C; o.K = C; o.st_mode = ST_ROW; o.ldc = C;
     choose_split(o, ws);
     HIP_TRY(launch_igemm(o, st));
+    if (!ff) return DANRA_OK;
+    IGemmArgs f1 = blank_args();
+    f1.A = attended; f1.lda = C; f1.ln = 1; f1.a_mode = A_GEMM;
+    f1.W = at.w_ff1; f1.bias = at.b_ff1; f1.act = ACT_GELU; f1.out = ws.obuf;
+    f1.M = B * L; f1.N = C; f1.K = C; f1.st_mode = ST_ROW; f1.ldc = C;
+    choose_split(f1, ws);
+    HIP_TRY(launch_igemm(f1, st));
+    IGemmArgs f2 = blank_args();
+    f2.A = ws.obuf; f2.lda = C; f2.a_mode = A_GEMM;
+    f2.W = at.w_ff2; f2.bias = at.b_ff2; f2.res = attended; f2.ldr = C; f2.act = relu ? ACT_RELU : ACT_NONE; f2.out = out;
+    f2.M = B * L; f2.N = C; f2.K = C; f2.st_mode = ST_ROW; f2.ldc = C;
+    choose_split(f2, ws);
+    HIP_TRY(launch_igemm(f2, st));
     return DANRA_OK;
 }
 
@@ -709,6 +765,7 @@ int danra_destroy(danra_handle_t h) {
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->tb_table) (void)hipFree(h->tb_table);
+    if (h->tb_table_u) (void)hipFree(h->tb_table_u);
     if (h->tb_index) (void)hipFree(h->tb_index);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     delete h;
@@ -818,7 +875,21 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,
                  void* stream) {
+    return danra_sample_guided(h, x, y, cond, lsm, topo, B, H, W, T, betas, alphas, alpha_hat, noise_mode, noise, seed,
+                               0.0f, 1.0f, trace_steps, n_trace, trace, stream);
+}
+
+int danra_sample_guided(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm,
+                        const float* topo, int B, int H, int W, int T, const float* betas, const float* alphas,
+                        const float* alpha_hat, int noise_mode, const float* noise, uint64_t seed, float cfg_scale,
+                        float noise_scale, const int* trace_steps, int n_trace, float* trace, void* stream) {
     RC_TRY(check_ready(h, B, H, W));
+    // The unconditional evaluation of a guided step passes no label and no conditioning plane
+    // (DDPM_clean_application/src/diffusion_modules.py:158), so the network must not expect any plane.
+    const bool guided = cfg_scale > 0.0f;
+    if (guided && h->in_channels != 1)
+        return fail(DANRA_EINVAL, "classifier-free guidance evaluates the network without conditioning planes, "
+                                  "but conv1 of this network expects %d input channels", h->in_channels);
     if (!x || !betas || !alphas || !alpha_hat || T < 2) return fail(DANRA_EINVAL, "bad sampling arguments");
     if (h->cfg.out_channels != 1) return fail(DANRA_EINVAL, "sampling needs out_channels == 1 (eps has x's shape)");
     if (noise_mode == DANRA_NOISE_HOST && T > 2 && !noise) return fail(DANRA_EINVAL, "host-noise mode needs noise_dev");
@@ -846,13 +917,26 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
     if (h->cfg.has_lsm) HIP_TRY(hipMemcpyAsync(ws.lsms, lsm, n * 4, hipMemcpyDeviceToDevice, st));
     if (h->cfg.has_topo) HIP_TRY(hipMemcpyAsync(ws.topos, topo, n * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(launch_init_state(ws.state, T - 1, noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed,
-                              noise_mode == DANRA_NOISE_HOST ? noise : nullptr, st));
+                              noise_mode == DANRA_NOISE_HOST ? noise : nullptr, cfg_scale, noise_scale, st));
     RC_TRY(upload_freq(h, st));
 
-    // the time projections of every (timestep, class) pair, tabulated once: [T][classes][width]
+    // the time projections of every (timestep, class) pair, tabulated once: [T][classes][width]; a guided
+    // loop with labels also tabulates the label-free rows [T][width] for its unconditional evaluations
+    // (a separate allocation, so that no pointer a captured step holds depends on T)
     const int classes = has_y ? h->cfg.num_classes : 1;
+    const bool two_tables = guided && has_y;
+    const size_t rows_cond = (size_t)T * classes;
+    if (two_tables && (size_t)T > h->tb_u_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h->tb_table_u) (void)hipFree(h->tb_table_u);
+        h->tb_table_u = nullptr; h->tb_u_cap = 0;
+        drop_step_graph(ws);
+        if (hipMalloc((void**)&h->tb_table_u, (size_t)T * h->tb_width * sizeof(float)) != hipSuccess)
+            return fail(DANRA_ENOMEM, "label-free time-projection table of %d rows: allocation failed", T);
+        h->tb_u_cap = (size_t)T;
+    }
     {
-        const size_t rows = (size_t)T * classes;
+        const size_t rows = rows_cond + (two_tables ? (size_t)T : 0);
         if (rows > h->tb_rows_cap) {
             HIP_TRY(hipStreamSynchronize(st));
             if (h->tb_table) (void)hipFree(h->tb_table);
@@ -865,14 +949,21 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
             h->tb_rows_cap = rows;
         }
         h->h_tb_index.resize(2 * rows);
-        for (size_t r = 0; r < rows; ++r) {
+        for (size_t r = 0; r < rows_cond; ++r) {
             h->h_tb_index[r] = (int64_t)(r / classes);
             h->h_tb_index[rows + r] = (int64_t)(r % classes);
         }
+        for (size_t r = rows_cond; r < rows; ++r) {
+            h->h_tb_index[r] = (int64_t)(r - rows_cond);
+            h->h_tb_index[rows + r] = 0;
+        }
         HIP_TRY(hipMemcpyAsync(h->tb_index, h->h_tb_index.data(), 2 * rows * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        RC_TRY(run_time_mlp(h, h->tb_index, nullptr, has_y ? h->tb_index + rows : nullptr, (int)rows, nullptr, nullptr,
+        RC_TRY(run_time_mlp(h, h->tb_index, nullptr, has_y ? h->tb_index + rows : nullptr, (int)rows_cond, nullptr, nullptr,
                             h->tb_table, st));
+        if (two_tables)
+            RC_TRY(run_time_mlp(h, h->tb_index + rows_cond, nullptr, nullptr, T, nullptr, nullptr, h->tb_table_u, st));
     }
+    const float* tb_uncond = two_tables ? h->tb_table_u : h->tb_table;
     // the conditioning planes' share of the stem convolution is the same at every step
     if (h->stem.Cin > 1) {
         const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -886,7 +977,10 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
     auto enqueue_step = [&](hipStream_t s) -> int {
         RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, has_y ? ws.ys : nullptr, ws.conds, ws.lsms, ws.topos, ws.eps, B,
                             H, W, s, true, h->tb_table));
-        HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, ws.coef, ws.state, n, s));
+        if (guided)
+            RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, nullptr, nullptr, nullptr, nullptr, ws.eps_uncond, B, H, W, s,
+                                true, tb_uncond));
+        HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, guided ? ws.eps_uncond : nullptr, ws.coef, ws.state, n, s));
         return DANRA_OK;
     };
 
@@ -895,7 +989,8 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
     // otherwise slow the very loop that is being measured).
     constexpr int kProfStride = 8;
     const bool use_graph = h->graph_mode != 0;
-    if (use_graph && (!ws.step_exec || ws.step_exec_has_y != (int)has_y)) {
+    const int step_mode = (has_y ? 1 : 0) | (guided ? 2 : 0);
+    if (use_graph && (!ws.step_exec || ws.step_exec_mode != step_mode)) {
         h->prof_now = false;
         drop_step_graph(ws);
         if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -912,7 +1007,7 @@ int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond
             drop_step_graph(ws);
             return fail(DANRA_EHIP, "instantiating the denoise-step graph failed: %s", hipGetErrorString(ie));
         }
-        ws.step_exec_has_y = (int)has_y;
+        ws.step_exec_mode = step_mode;
     }
     for (int i = T - 1; i >= 1; --i) {
         h->prof_now = h->prof_kind != 0 && (i % kProfStride == 0);

@@ -10,13 +10,14 @@ namespace danra {
 // ---------------------------------------------------------------- implicit GEMM (convs, linears)
 enum AMode { A_GEMM = 0, A_CONV = 1, A_CONV1 = 2 };
 enum StoreMode { ST_ROW = 0, ST_QKV = 1, ST_CONVT = 2 };
+enum Activation { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 // out[m][n] = epilogue( sum_k A(m,k) * W[n][k] ).
 //   A_GEMM : A(m,k) = A[m*lda + k], optionally LayerNorm-ed per row over the whole K (ln=1).
 //   A_CONV : NHWC input, k = (kh, kw, c), zero padding; optional per-(image,channel) normalisation
 //            (x - nmean) * nrstd of the in-bounds taps (InstanceNorm applied on load).
 //   A_CONV1: up to four [B][Hi][Wi] planes, k = (plane, kh, kw)  (the network's 8x8 stride-2 stem).
-// epilogue: v += bias[n]; v += res[m*ldr+n]; relu; v += tbias[(m / rows_per_img)*tb_stride + n]; store.
+// epilogue: v += bias[n]; v += res[m*ldr+n]; act (none / ReLU / exact GELU); v += tbias[(m / rows_per_img)*tb_stride + n]; store.
 struct IGemmArgs {
     const float* A;
     const float* planes[4];
@@ -35,7 +36,7 @@ struct IGemmArgs {
     int a_mode;
     int ln;
     int Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad;
-    int ldr, relu, tb_stride, rows_per_img;
+    int ldr, act, tb_stride, rows_per_img;
     int st_mode, ldc;
     int qkv_C, qkv_hd, qkv_L, qkv_heads;
     long long qkv_plane;
@@ -68,12 +69,15 @@ struct SampleState {
     int philox;                // 1: z drawn in-kernel (Philox), 0: z read from `noise`
     unsigned long long seed;
     const float* noise;        // host-noise mode: [T-2][n] draws in draw order (timestep T-1 first), or null
+    float cfg_scale;           // classifier-free guidance weight (used when the update is given two predictions)
+    float noise_scale;         // every draw is multiplied by this (1, or 0.005 for the "scaled data" mode)
 };
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
-                             hipStream_t stream);
-// x <- c1*(x - c2*eps) + c3*z with (c1, c2, c3) = coef[state->t_upd] and z = 0 at timestep 1.
-hipError_t launch_ddpm_update_state(float* x, const float* eps, const float4* coef, SampleState* state, size_t n,
-                                    hipStream_t stream);
+                             float cfg_scale, float noise_scale, hipStream_t stream);
+// x <- c1*(x - c2*eps) + c3*(noise_scale*z) with (c1, c2, c3) = coef[state->t_upd] and z = 0 at timestep 1.
+// With eps_uncond != null, eps is first replaced by lerp(eps_uncond, eps, cfg_scale).
+hipError_t launch_ddpm_update_state(float* x, const float* eps, const float* eps_uncond, const float4* coef,
+                                    SampleState* state, size_t n, hipStream_t stream);
 
 struct TimeMlpArgs {
     const int64_t* t;          // [B], or null when `state` supplies one timestep for every row
@@ -121,7 +125,8 @@ hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_
                             hipStream_t stream);
 hipError_t launch_pack_convT(const float* w_iokk, const float* bias, float* w_out, float* bias_out, int Ci, int Co,
                              hipStream_t stream);
+// LayerNorm(C) affine folded into the Linear(C -> rows) behind it
 hipError_t launch_pack_inproj(const float* w_in, const float* b_in, const float* ln_g, const float* ln_b,
-                              float* w_out, float* b_out, int C, hipStream_t stream);
+                              float* w_out, float* b_out, int rows, int C, hipStream_t stream);
 
 }  // namespace danra

@@ -63,10 +63,23 @@ __device__ __forceinline__ unsigned long long col_offset(const IGemmArgs& p, int
     return ((unsigned long long)(q >> 1) * 2 * p.ct_W + (q & 1)) * p.ct_C + co;
 }
 
+// Exact (erf) GELU, as torch.nn.GELU() evaluates it.
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float activate(int act, float v) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_GELU) return gelu(v);
+    return v;
+}
+__device__ __forceinline__ float4 activate(int act, float4 v) {
+    if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (act == ACT_GELU) { v.x = gelu(v.x); v.y = gelu(v.y); v.z = gelu(v.z); v.w = gelu(v.w); }
+    return v;
+}
+
 __device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias, int m, int n, int img) {
     v += bias;
     if (p.res) v += p.res[(size_t)m * p.ldr + n];
-    if (p.relu) v = fmaxf(v, 0.f);
+    v = activate(p.act, v);
     if (p.tbias) v += p.tbias[(size_t)img * p.tb_stride + n];
     return v;
 }
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rowOut[row] * p.ldr + n);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        v = activate(p.act, v);
         if (p.tbias) {
             const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)rowImg[row] * p.tb_stride + n);
             v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             float4 v = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            v = activate(p.act, v);
             if (m0 + orow + 8 * j < p.M) *reinterpret_cast<float4*>(p.out + roff4[j] + co) = v;
         }
     }

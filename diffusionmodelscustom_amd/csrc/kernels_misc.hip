@@ -630,11 +630,24 @@ hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, fl
 // The same update driven by the device-resident sampler state (see SampleState): coefficients come from
 // a per-timestep table, the timestep-1 update adds no noise, and block 0 hands the next timestep to the
 // next UNet evaluation.
+// torch.lerp(start, end, w) as ATen's vectorised kernel forms it: fma(w, end - start, start) for |w| < 0.5,
+// fma(w - 1, end - start, end) otherwise.
+__device__ __forceinline__ float lerp_one(float start, float end, float w) {
+    const float diff = end - start;
+    return fabsf(w) < 0.5f ? fmaf(w, diff, start) : fmaf(w - 1.0f, diff, end);
+}
+__device__ __forceinline__ float scale_one(float z, float s) {
+#pragma clang fp contract(off)
+    return z * s;
+}
+
 __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x, const float* __restrict__ eps,
+                                                           const float* __restrict__ eps_uncond,
                                                            const float4* __restrict__ coef, SampleState* state,
                                                            size_t n4) {
     const int t = state->t_upd;
     const float4 c = coef[t];
+    const float guide = state->cfg_scale, zs = state->noise_scale;
     const bool noisy = t > 1;
     const bool philox = noisy && state->philox;
     const unsigned long long seed = state->seed;
@@ -642,7 +655,12 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
                                                                   : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 xv = reinterpret_cast<float4*>(x)[i];
-        const float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        if (eps_uncond) {
+            const float4 uv = reinterpret_cast<const float4*>(eps_uncond)[i];
+            ev.x = lerp_one(uv.x, ev.x, guide); ev.y = lerp_one(uv.y, ev.y, guide);
+            ev.z = lerp_one(uv.z, ev.z, guide); ev.w = lerp_one(uv.w, ev.w, guide);
+        }
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (philox) {
             uint32_t r[4];
@@ -652,6 +670,8 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
         } else if (noise) {
             z = reinterpret_cast<const float4*>(noise)[i];
         }
+        // noise *= scale (the product with 1.0f is exact, so unscaled sampling is unchanged)
+        z.x = scale_one(z.x, zs); z.y = scale_one(z.y, zs); z.z = scale_one(z.z, zs); z.w = scale_one(z.w, zs);
         xv.x = ddpm_one(xv.x, ev.x, z.x, c.x, c.y, c.z);
         xv.y = ddpm_one(xv.y, ev.y, z.y, c.x, c.y, c.z);
         xv.z = ddpm_one(xv.z, ev.z, z.z, c.x, c.y, c.z);
@@ -661,13 +681,13 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
     if (blockIdx.x == 0 && threadIdx.x == 0) state->t_fwd = t - 1;
 }
 
-hipError_t launch_ddpm_update_state(float* x, const float* eps, const float4* coef, SampleState* state, size_t n,
-                                    hipStream_t stream) {
+hipError_t launch_ddpm_update_state(float* x, const float* eps, const float* eps_uncond, const float4* coef,
+                                    SampleState* state, size_t n, hipStream_t stream) {
     if (n % 4) return hipErrorInvalidValue;
     const size_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_ddpm_update_state, dim3(blocks), dim3(256), 0, stream, x, eps, coef, state, n4);
+    hipLaunchKernelGGL(k_ddpm_update_state, dim3(blocks), dim3(256), 0, stream, x, eps, eps_uncond, coef, state, n4);
     return hipGetLastError();
 }
 
@@ -726,7 +746,8 @@ hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alp
     return hipGetLastError();
 }
 
-__global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise) {
+__global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
+                             float cfg_scale, float noise_scale) {
     if (threadIdx.x == 0) {
         s->t_fwd = t_start;
         s->t_upd = t_start;
@@ -734,11 +755,14 @@ __global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned l
         s->philox = philox;
         s->seed = seed;
         s->noise = noise;
+        s->cfg_scale = cfg_scale;
+        s->noise_scale = noise_scale;
     }
 }
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
-                             hipStream_t stream) {
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, stream, s, t_start, philox, seed, noise);
+                             float cfg_scale, float noise_scale, hipStream_t stream) {
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, stream, s, t_start, philox, seed, noise, cfg_scale,
+                       noise_scale);
     return hipGetLastError();
 }
 
@@ -824,7 +848,7 @@ hipError_t launch_pack_convT(const float* w, const float* bias, float* wout, flo
 
 __global__ void k_pack_inproj(const float* w_in, const float* b_in, const float* g, const float* be, float* wout,
                               float* bout, int C) {
-    // LayerNorm affine folded into in_proj: W'[n][k] = W[n][k]*g[k]; b'[n] = b[n] + sum_k W[n][k]*beta[k]
+    // LayerNorm affine folded into the Linear that follows it (one block per output row): W'[n][k] = W[n][k]*g[k]; b'[n] = b[n] + sum_k W[n][k]*beta[k]
     const int n = blockIdx.x;
     __shared__ double red[256];
     double s = 0.0;
@@ -842,8 +866,8 @@ __global__ void k_pack_inproj(const float* w_in, const float* b_in, const float*
     if (threadIdx.x == 0) bout[n] = (float)((double)b_in[n] + red[0]);
 }
 hipError_t launch_pack_inproj(const float* w_in, const float* b_in, const float* g, const float* be, float* wout,
-                              float* bout, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pack_inproj, dim3(3 * C), dim3(256), 0, stream, w_in, b_in, g, be, wout, bout, C);
+                              float* bout, int rows, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_inproj, dim3(rows), dim3(256), 0, stream, w_in, b_in, g, be, wout, bout, C);
     return hipGetLastError();
 }
 

@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
             const int Ho = (s.Hi + 2 * s.pad - s.k) / s.stride + 1, Wo = (s.Wi + 2 * s.pad - s.k) / s.stride + 1;
             a.M = s.B * Ho * Wo; a.N = s.Cout; a.K = s.k * s.k * s.Cin; a.a_mode = A_CONV;
             a.Hi = s.Hi; a.Wi = s.Wi; a.Cin = s.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = s.k; a.KW = s.k; a.stride = s.stride; a.pad = s.pad;
-            a.res = res; a.ldr = s.Cout; a.relu = 1; a.rows_per_img = Ho * Wo; a.st_mode = ST_ROW; a.ldc = s.Cout;
+            a.res = res; a.ldr = s.Cout; a.act = 1; a.rows_per_img = Ho * Wo; a.st_mode = ST_ROW; a.ldc = s.Cout;
         } else {
             a.M = s.B * s.Hi * s.Wi; a.N = s.Cout; a.K = s.Cin; a.a_mode = A_GEMM; a.lda = s.Cin; a.ln = s.ln;
             a.st_mode = s.st_mode; a.ldc = s.Cout;

@@ -93,15 +93,11 @@ class DiffusionUtils:
 
     def _sample_hip(self, x, model, y, cond_img, lsm_cond, topo_cond, host_noise):
         engine = model.hip_engine(x.device)
-        e = model.encoder
         x = x.detach().clone().contiguous()  # the reference returns a new tensor and leaves its input untouched
         if host_noise is not None:
             host_noise = host_noise.to(device=x.device, dtype=torch.float32)
             assert host_noise.shape[0] >= self.n_timesteps - 2, 'need one noise tensor per step with i > 1'
-        return engine.sample(x, y if hasattr(e, 'label_emb') else None,
-                             cond_img if e.cond_on_img else None,
-                             lsm_cond if hasattr(e, 'lsm') else None,
-                             topo_cond if hasattr(e, 'elevation') else None,
+        return engine.sample(x, *model.hip_call_arguments(y, cond_img, lsm_cond, topo_cond),
                              self.betas, self.alphas, self.alpha_hat, noise=host_noise, seed=self._philox_seed())
 
     def _sample_generic(self, x, model, y, cond_img, lsm_cond, topo_cond, host_noise):

@@ -28,6 +28,7 @@ class DanraConfig(ctypes.Structure):
         ("out_channels", ctypes.c_int),
         ("n_heads", ctypes.c_int),
         ("block_layers", ctypes.c_int * 4),
+        ("attn_ff", ctypes.c_int),
     ]
 
 
@@ -49,6 +50,9 @@ _SIGNATURES = {
                                                 ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_sample": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, _P, ctypes.c_int, _P, _P]),
+    "danra_sample_guided": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           _P, _P, _P, ctypes.c_int, _P, ctypes.c_uint64, ctypes.c_float, ctypes.c_float,
+                                           _P, ctypes.c_int, _P, _P]),
     "danra_noise_image": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
@@ -158,11 +162,11 @@ class UNetEngine:
     packing, owns its packed-weight arena and activation workspace."""
 
     def __init__(self, *, has_lsm, has_topo, has_cond, num_classes, time_embedding, out_channels, n_heads,
-                 block_layers, device):
+                 block_layers, device, attn_ff=False):
         self.lib = load_library()
         self.device = torch.device(device)
         cfg = DanraConfig(int(has_lsm), int(has_topo), int(has_cond), int(num_classes or 0), int(time_embedding),
-                          int(out_channels), int(n_heads), (ctypes.c_int * 4)(*block_layers))
+                          int(out_channels), int(n_heads), (ctypes.c_int * 4)(*block_layers), int(bool(attn_ff)))
         self.cfg = cfg
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -251,9 +255,10 @@ class UNetEngine:
         return tuple(outs)
 
     def sample(self, x, y, cond_img, lsm_cond, topo_cond, betas, alphas, alpha_hat, noise=None, seed=0,
-               trace_steps=None):
+               trace_steps=None, cfg_scale=0.0, noise_scale=1.0):
         """Whole reverse loop on the device.  x is updated in place and returned.  `noise` (a CUDA
-        tensor [(T-2), B, 1, H, W]) selects host-noise mode, otherwise Philox noise from `seed`."""
+        tensor [(T-2), B, 1, H, W]) selects host-noise mode, otherwise Philox noise from `seed`.
+        cfg_scale > 0: classifier-free guidance (two evaluations per step); noise_scale multiplies every draw."""
         x = _f32(x, "x")
         B, _, H, W = x.shape
         T = int(betas.numel())
@@ -272,11 +277,12 @@ class UNetEngine:
         yy = _i64(y, "y")
         cc, ll, tt = _f32(cond_img, "cond_img"), _f32(lsm_cond, "lsm_cond"), _f32(topo_cond, "topo_cond")
         with torch.cuda.device(x.device):
-            _check(self.lib, self.lib.danra_sample(
+            _check(self.lib, self.lib.danra_sample_guided(
                 self.handle, _ptr(x), _ptr(yy), _ptr(cc), _ptr(ll), _ptr(tt), B, H, W, T, _ptr(hb), _ptr(ha), _ptr(hh),
-                mode, _ptr(noise), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                mode, _ptr(noise), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ctypes.c_float(float(cfg_scale)),
+                ctypes.c_float(float(noise_scale)),
                 ctypes.cast(steps_arr, ctypes.c_void_p) if steps_arr is not None else None, n_trace, _ptr(trace),
-                _stream()), "danra_sample")
+                _stream()), "danra_sample_guided")
             # the launches above borrow yy/cc/ll/tt/noise: keep them alive until the stream has run them
             for keep in (yy, cc, ll, tt, noise):
                 if keep is not None:

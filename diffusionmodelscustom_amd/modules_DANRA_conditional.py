@@ -115,10 +115,9 @@ class Encoder(ResNet):
     def make_attention_layers(self, fmap_channels: Iterable[int]):
         return nn.ModuleList([ImageSelfAttention(ch, self.n_heads) for ch in fmap_channels])
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
-                cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
-                topo_cond: Optional[torch.Tensor] = None):
-        # channel order x, lsm, topo, cond (reference modules:228-238)
+    def input_planes(self, x, cond_img, lsm_cond, topo_cond):
+        """The tensors concatenated in front of conv1, channel order x, lsm, topo, cond (reference modules:228-238):
+        lsm/topo whenever the buffers were registered, cond_img whenever it is passed."""
         planes = [x]
         if hasattr(self, 'lsm'):
             planes.append(lsm_cond)
@@ -126,6 +125,12 @@ class Encoder(ResNet):
             planes.append(topo_cond)
         if cond_img is not None:
             planes.append(cond_img)
+        return planes
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
+                cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
+                topo_cond: Optional[torch.Tensor] = None):
+        planes = self.input_planes(x, cond_img, lsm_cond, topo_cond)
         x = torch.cat(planes, dim=1) if len(planes) > 1 else x
 
         emb = self.pos_encoding(t.unsqueeze(-1).type(torch.float), self.time_embedding)
@@ -149,6 +154,8 @@ class DecoderBlock(nn.Module):
     """convT(k2,s2) - IN - conv3x3 - IN - (+skip) - (+time bias, attention) - activation
     (reference modules:349-460)."""
 
+    attention_class = ImageSelfAttention  # a variant of the network swaps in its own attention block
+
     def __init__(self, input_channels: int, output_channels: int, time_embedding: int, upsample_scale: int = 2,
                  activation: nn.Module = nn.ReLU, compute_attn: bool = True, n_heads: int = 4):
         super().__init__()
@@ -158,7 +165,7 @@ class DecoderBlock(nn.Module):
         self.time_embedding = time_embedding
         self.compute_attn = compute_attn
         self.n_heads = n_heads
-        self.attention = ImageSelfAttention(self.output_channels, self.n_heads) if compute_attn else nn.Identity()
+        self.attention = self.attention_class(self.output_channels, self.n_heads) if compute_attn else nn.Identity()
         self.sinusiodal_embedding = SinusoidalEmbedding(self.time_embedding)
         self.time_projection_layer = nn.Sequential(nn.SiLU(), nn.Linear(self.time_embedding, self.output_channels))
         self.transpose = nn.ConvTranspose2d(self.input_channels, self.input_channels,
@@ -168,10 +175,14 @@ class DecoderBlock(nn.Module):
         self.instance_norm2 = nn.InstanceNorm2d(self.conv.out_channels)
         self.activation = activation()
 
+    @staticmethod
+    def shape_mismatch_message(prev_fmap, out):
+        return 'feature maps must be of same shape'
+
     def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
         out = self.instance_norm2(self.conv(self.instance_norm1(self.transpose(fmap))))
         if torch.is_tensor(prev_fmap):
-            assert (prev_fmap.shape == out.shape), 'feature maps must be of same shape'
+            assert (prev_fmap.shape == out.shape), self.shape_mismatch_message(prev_fmap, out)
             out = out + prev_fmap
         if torch.is_tensor(t):
             t_emb = self.time_projection_layer(self.sinusiodal_embedding(t))
@@ -183,6 +194,8 @@ class Decoder(nn.Module):
     """Four up-sampling blocks with additive skips and a final 64 -> output_channels block
     (reference modules:465-569)."""
 
+    block_class = DecoderBlock
+
     def __init__(self, last_fmap_channels: int, output_channels: int, time_embedding: int,
                  first_fmap_channels: int = 64, n_heads: int = 4):
         super().__init__()
@@ -192,7 +205,7 @@ class Decoder(nn.Module):
         self.first_fmap_channels = first_fmap_channels
         self.n_heads = n_heads
         self.residual_layers = self.make_layers()
-        self.final_layer = DecoderBlock(self.residual_layers[-1].input_channels, self.output_channels,
+        self.final_layer = self.block_class(self.residual_layers[-1].input_channels, self.output_channels,
                                         time_embedding=self.time_embedding, activation=nn.Identity,
                                         compute_attn=False, n_heads=self.n_heads)
         self.final_layer.instance_norm2 = nn.Identity()
@@ -202,7 +215,7 @@ class Decoder(nn.Module):
         in_ch = self.last_fmap_channels
         for i in range(n):
             out_ch = in_ch // 2 if i != (n - 1) else self.first_fmap_channels
-            layers.append(DecoderBlock(in_ch, out_ch, time_embedding=self.time_embedding, compute_attn=True,
+            layers.append(self.block_class(in_ch, out_ch, time_embedding=self.time_embedding, compute_attn=True,
                                        n_heads=self.n_heads))
             in_ch = out_ch
         return nn.ModuleList(layers)
@@ -227,14 +240,34 @@ class DiffusionNet(nn.Module):
         self._hip_signature = None
 
     # ------------------------------------------------------------------ HIP path plumbing
+    encoder_class = Encoder
+    decoder_class = Decoder
+
+    def hip_geometry(self):
+        """Which conditioning planes conv1 expects and which attention block the network uses."""
+        e = self.encoder
+        return dict(has_lsm=hasattr(e, 'lsm'), has_topo=hasattr(e, 'elevation'), has_cond=bool(e.cond_on_img),
+                    attn_ff=False)
+
+    def hip_call_arguments(self, y, cond_img, lsm_cond, topo_cond):
+        """(y, cond_img, lsm_cond, topo_cond) as the native library takes them for this network."""
+        e = self.encoder
+        if not e.cond_on_img and cond_img is not None:
+            self._reject_unexpected_cond()
+        return (y if hasattr(e, 'label_emb') else None, cond_img if e.cond_on_img else None,
+                lsm_cond if hasattr(e, 'lsm') else None, topo_cond if hasattr(e, 'elevation') else None)
+
     def hip_supported(self):
         """True when the model has the geometry the native library implements (every reference driver's)."""
         e, d = self.encoder, self.decoder
-        return (isinstance(e, Encoder) and isinstance(d, Decoder) and e.block is BasicBlock
+        if not (isinstance(e, self.encoder_class) and isinstance(d, self.decoder_class)):
+            return False
+        g = self.hip_geometry()
+        return (e.block is BasicBlock
                 and len(e.block_layers) == 4 and e.n_heads == 4 and d.n_heads == 4
                 and e.time_embedding == d.time_embedding and e.time_embedding % 8 == 0 and e.time_embedding <= 512
                 and d.last_fmap_channels == 512 and d.first_fmap_channels == 64 and 1 <= d.output_channels <= 4
-                and e.conv1.in_channels == 1 + int(hasattr(e, 'lsm')) + int(hasattr(e, 'elevation')) + int(e.cond_on_img))
+                and e.conv1.in_channels == 1 + int(g['has_lsm']) + int(g['has_topo']) + int(g['has_cond']))
 
     def _hip_eligible(self, x):
         return (not self.training and not torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
@@ -247,10 +280,9 @@ class DiffusionNet(nn.Module):
         device = torch.device(device)
         if self._hip is None or self._hip[1] != device:
             e = self.encoder
-            engine = UNetEngine(has_lsm=hasattr(e, 'lsm'), has_topo=hasattr(e, 'elevation'), has_cond=e.cond_on_img,
-                                num_classes=e.num_classes or 0, time_embedding=e.time_embedding,
+            engine = UNetEngine(num_classes=e.num_classes or 0, time_embedding=e.time_embedding,
                                 out_channels=self.decoder.output_channels, n_heads=e.n_heads,
-                                block_layers=list(e.block_layers), device=device)
+                                block_layers=list(e.block_layers), device=device, **self.hip_geometry())
             self._hip = (engine, device)
             self._hip_signature = None
         engine = self._hip[0]
@@ -265,10 +297,7 @@ class DiffusionNet(nn.Module):
                 cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
                 topo_cond: Optional[torch.Tensor] = None):
         if self._hip_eligible(x):
-            if not self.encoder.cond_on_img:
-                cond_img = None if cond_img is None else self._reject_unexpected_cond()
-            return self.hip_engine(x.device).forward(x, t, y if hasattr(self.encoder, 'label_emb') else None,
-                                                     cond_img, lsm_cond, topo_cond)
+            return self.hip_engine(x.device).forward(x, t, *self.hip_call_arguments(y, cond_img, lsm_cond, topo_cond))
         enc_fmaps = self.encoder(x, t=t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)
         return self.decoder(*enc_fmaps, t=t)
 

@@ -42,6 +42,11 @@ typedef struct {
     int out_channels;    /* Decoder output_channels (1) */
     int n_heads;         /* 4 */
     int block_layers[4]; /* BasicBlocks per ResNet layer ([2,2,2,2]) */
+    int attn_ff;         /* 0: the network of DDPM_DANRA_conditional/modules_DANRA_conditional.py.
+                          * 1: the network of DDPM_clean_application/src/unet.py: every ImageSelfAttention names its
+                          *    MultiheadAttention `.mha` (unet.py:87) and ends with the feed-forward block
+                          *    x + Linear(GELU(Linear(LayerNorm(x)))) (`.ff`, unet.py:91-96,116); has_lsm / has_topo /
+                          *    has_cond then mean Encoder(cond_on_lsm / cond_on_topo / cond_on_img) (unet.py:163-168) */
 } danra_config_t;
 
 const char* danra_last_error(void);
@@ -115,6 +120,19 @@ int danra_sample(danra_handle_t h, float* x_dev, const int64_t* y_dev, const flo
                  const float* noise_dev, uint64_t seed, const int* trace_steps, int n_trace,
                  float* trace_dev, void* stream);
 
+/* Replaces DiffusionUtils.sample of DDPM_clean_application/src/diffusion_modules.py:101-186: the same loop with
+ *  - classifier-free guidance (cfg_scale > 0, :156-160): every step evaluates the network twice, with and without the
+ *    label (no conditioning planes in either call, so the network must have been built without any), and uses
+ *    torch.lerp(eps_uncond, eps_cond, cfg_scale);
+ *  - noise_scale: every Gaussian draw is multiplied by it before use (`noise *= 0.005` when data_scaled, :173-174;
+ *    pass 1 otherwise).  Scaling the start image (:131-132) is the caller's job, x_dev is taken as given.
+ * danra_sample(...) == danra_sample_guided(..., cfg_scale = 0, noise_scale = 1, ...). */
+int danra_sample_guided(danra_handle_t h, float* x_dev, const int64_t* y_dev, const float* cond_dev,
+                        const float* lsm_dev, const float* topo_dev, int B, int H, int W, int T,
+                        const float* betas, const float* alphas, const float* alpha_hat, int noise_mode,
+                        const float* noise_dev, uint64_t seed, float cfg_scale, float noise_scale,
+                        const int* trace_steps, int n_trace, float* trace_dev, void* stream);
+
 /* Replaces DiffusionUtils.noiseImage (diffusion_DANRA_conditional.py:85-103), the forward process used by the
  * training step: noisy = sqrt(alpha_hat[t_b]) * x + sqrt(1 - alpha_hat[t_b]) * noise for image b, every operation
  * rounded to fp32 as torch evaluates the three tensor expressions.  alpha_hat_dev: DiffusionUtils.alpha_hat (device,
@@ -152,8 +170,9 @@ int danra_tbias_width(danra_handle_t h);
 int danra_time_embed(danra_handle_t h, const int64_t* t_dev, const int64_t* y_dev, int B,
                      float* enc_emb_out, float* dec_emb_out, float* tbias_out, void* stream);
 
-/* ImageSelfAttention.forward (modules:91-110) of attention layer `index` (0..4 encoder levels,
- * 5..8 decoder blocks) on NHWC tokens; relu = the decoder's trailing activation (modules:459). */
+/* ImageSelfAttention.forward (modules:91-110; with attn_ff, DDPM_clean_application/src/unet.py:98-119) of attention
+ * layer `index` (0..4 encoder levels, 5..8 decoder blocks) on NHWC tokens; relu = the decoder's trailing
+ * activation (modules:459). */
 int danra_attention(danra_handle_t h, int index, const float* x_nhwc, float* out_nhwc, int B, int HW,
                     int relu, void* stream);
 

@@ -6,7 +6,8 @@ CPU baseline of ``bench.py``.  Only ``tests/``, ``__graft_entry__.smoke()`` and 
 
 It is a functional (state_dict in, tensors out) restatement in torch CPU fp32 ops of
 /root/reference/DDPM_DANRA_conditional/{diffusion,modules}_DANRA_conditional.py, each function
-citing the lines it follows.  Parity pin: ``tests/test_oracle_golden.py`` checks every function
+citing the lines it follows.  Functions taking ``clean=True`` (and those named ``*_clean``) restate the
+variant in /root/reference/DDPM_clean_application/src/{unet,diffusion_modules}.py instead.  Parity pin: ``tests/test_oracle_golden.py`` checks every function
 here against ``tests/golden/*.npz``, which ``oracle/make_golden.py`` produced by importing and
 running the reference's own code in the build container (the reference holds no tests or golden
 vectors of its own for this path).
@@ -117,6 +118,26 @@ def image_self_attention(sd, prefix, x, n_heads=4, faithful=False):
     return o.permute(0, 2, 1).reshape(-1, C, H, W)
 
 
+def image_self_attention_clean(sd, prefix, x, n_heads=4):
+    """DDPM_clean_application/src/unet.py:98-119: LayerNorm -> self-attention (`.mha`) -> + x, then
+    + ff(.) with ff = LayerNorm -> Linear -> exact GELU -> Linear (:91-96)."""
+    B, C, H, W = x.shape
+    mapped = {prefix + ".layernorm.weight": sd[prefix + ".layernorm.weight"],
+              prefix + ".layernorm.bias": sd[prefix + ".layernorm.bias"]}
+    for k in ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias"):
+        mapped[prefix + ".attention." + k] = sd[prefix + ".mha." + k]
+    a = image_self_attention(mapped, prefix, x, n_heads)
+    tok = a.reshape(-1, C, H * W).permute(0, 2, 1)
+    h = F.layer_norm(tok, (C,), sd[prefix + ".ff.0.weight"], sd[prefix + ".ff.0.bias"], 1e-5)
+    h = F.gelu(F.linear(h, sd[prefix + ".ff.1.weight"], sd[prefix + ".ff.1.bias"]))
+    h = F.linear(h, sd[prefix + ".ff.3.weight"], sd[prefix + ".ff.3.bias"])
+    return (tok + h).permute(0, 2, 1).reshape(-1, C, H, W)
+
+
+def _attention(sd, prefix, x, clean, faithful=False):
+    return image_self_attention_clean(sd, prefix, x) if clean else image_self_attention(sd, prefix, x, faithful=faithful)
+
+
 def _bn(sd, prefix, x):
     """BatchNorm2d in eval mode (diffusion_DANRA_conditional.py:122 puts the model in eval)."""
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
@@ -145,12 +166,13 @@ def resnet_layer(sd, prefix, x, stride):
     return x
 
 
-def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False):
-    """modules_DANRA_conditional.py:213-312."""
+def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False):
+    """modules_DANRA_conditional.py:213-312; clean: DDPM_clean_application/src/unet.py:217-316, where lsm/topo are
+    concatenated iff passed (:232-239) instead of iff the buffers exist."""
     p = "encoder."
-    if p + "lsm" in sd:
+    if (lsm_cond is not None) if clean else (p + "lsm" in sd):
         x = torch.cat([x, lsm_cond], dim=1)
-    if p + "elevation" in sd:
+    if (topo_cond is not None) if clean else (p + "elevation" in sd):
         x = torch.cat([x, topo_cond], dim=1)
     if cond_img is not None:
         x = torch.cat((x, cond_img), dim=1)
@@ -160,19 +182,19 @@ def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=No
     fmaps = []
     f = F.conv2d(x, sd[p + "conv1.weight"], None, 2, 3)
     f = f + time_projection(sd, p + "time_projection_layers.0", emb)[:, :, None, None]
-    f = image_self_attention(sd, p + "attention_layers.0", f, faithful=faithful)
+    f = _attention(sd, p + "attention_layers.0", f, clean, faithful)
     fmaps.append(f)
     h = F.conv2d(f, sd[p + "conv2.weight"], None, 2, 3)
     h = F.relu(_bn(sd, p + "bn1", h))
     for lvl in range(1, 5):
         h = resnet_layer(sd, f"{p}layer{lvl}", h, 1 if lvl == 1 else 2)
         h = h + time_projection(sd, f"{p}time_projection_layers.{lvl}", emb)[:, :, None, None]
-        h = image_self_attention(sd, f"{p}attention_layers.{lvl}", h, faithful=faithful)
+        h = _attention(sd, f"{p}attention_layers.{lvl}", h, clean, faithful)
         fmaps.append(h)
     return tuple(fmaps)
 
 
-def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithful=False):
+def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithful=False, clean=False):
     """modules_DANRA_conditional.py:425-460; ``final`` = the block built at :503-509
     (no second InstanceNorm, no attention, Identity activation)."""
     out = F.conv_transpose2d(fmap, sd[prefix + ".transpose.weight"], sd[prefix + ".transpose.bias"], stride=2)
@@ -186,23 +208,23 @@ def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithfu
     if t is not None:
         emb = decoder_sinusoidal_embedding(t, faithful=faithful)
         out = out + time_projection(sd, prefix + ".time_projection_layer", emb)[:, :, None, None]
-        out = image_self_attention(sd, prefix + ".attention", out, faithful=faithful)
+        out = _attention(sd, prefix + ".attention", out, clean, faithful)
     return out if final else F.relu(out)
 
 
-def decoder_forward(sd, fmaps, t, faithful=False):
-    """modules_DANRA_conditional.py:512-536."""
+def decoder_forward(sd, fmaps, t, faithful=False, clean=False):
+    """modules_DANRA_conditional.py:512-536 (clean: unet.py:516-540, the same)."""
     fm = list(reversed(fmaps))
-    out = decoder_block(sd, "decoder.residual_layers.0", fm[0], fm[1], t, faithful=faithful)
+    out = decoder_block(sd, "decoder.residual_layers.0", fm[0], fm[1], t, faithful=faithful, clean=clean)
     for idx in range(1, 4):
-        out = decoder_block(sd, f"decoder.residual_layers.{idx}", out, fm[idx + 1], t, faithful=faithful)
+        out = decoder_block(sd, f"decoder.residual_layers.{idx}", out, fm[idx + 1], t, faithful=faithful, clean=clean)
     return decoder_block(sd, "decoder.final_layer", out, final=True)
 
 
-def unet_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False):
-    """DiffusionNet.forward, modules_DANRA_conditional.py:597-616."""
-    fmaps = encoder_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, faithful=faithful)
-    return decoder_forward(sd, fmaps, t, faithful=faithful)
+def unet_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False):
+    """DiffusionNet.forward, modules_DANRA_conditional.py:597-616 (clean: unet.py:597-616)."""
+    fmaps = encoder_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, faithful=faithful, clean=clean)
+    return decoder_forward(sd, fmaps, t, faithful=faithful, clean=clean)
 
 
 # --------------------------------------------------------------------------- sampling loop
@@ -225,6 +247,53 @@ def sample(sd, x, n_timesteps, beta_min, beta_max, y=None, cond_img=None, lsm_co
             ah = alpha_hat[t][:, None, None, None]
             eps = unet_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, faithful=faithful)
             noise = noise_fn(i, x) if i > 1 else torch.zeros_like(x)
+            x = (1 / torch.sqrt(alpha)) * (x - ((1 - alpha) / torch.sqrt(1 - ah)) * eps)
+            x = x + torch.sqrt(beta) * noise
+            if trace is not None and i in trace.get("want", ()):
+                trace[i] = x.clone()
+    return x
+
+
+# --------------------------------------------------------------------------- clean-application sampler
+def beta_schedule_clean(n_timesteps, beta_min, beta_max, scheduler="linear"):
+    """DDPM_clean_application/src/diffusion_modules.py:51-69: linear, or 1 - abar_t/abar_{t-1} of the squared-cosine
+    abar, clipped to [1e-4, 0.9999]."""
+    assert scheduler in ("linear", "cosine"), "scheduler must be linear or cosine"
+    if scheduler == "linear":
+        return torch.linspace(beta_min, beta_max, n_timesteps)
+    t = torch.linspace(0, n_timesteps, n_timesteps + 1)
+    ft = torch.cos(((t / n_timesteps + 0.008) / 1.008) * np.pi / 2) ** 2
+    alphat = ft / ft[0]
+    betat = 1 - alphat[1:] / alphat[:-1]
+    return torch.clip(betat, 0.0001, 0.9999)
+
+
+def sample_clean(sd, x, n_timesteps, beta_min, beta_max, y=None, cond_img=None, lsm_cond=None, topo_cond=None,
+                 scheduler="linear", cfg_scale=0.0, data_scaled=False, noise_fn=None, trace=None):
+    """DiffusionUtils.sample, DDPM_clean_application/src/diffusion_modules.py:101-186, from the start image on
+    (``x`` is the randn draw of :129; the 0.005 shrink of :131-132 is applied here)."""
+    betas = beta_schedule_clean(n_timesteps, beta_min, beta_max, scheduler)
+    alphas = 1 - betas
+    alpha_hat = torch.cumprod(alphas, dim=0)
+    if noise_fn is None:
+        noise_fn = lambda i, x_: torch.randn_like(x_)  # noqa: E731
+    with torch.no_grad():
+        if data_scaled:
+            x = x * 0.005
+        for i in reversed(range(1, n_timesteps)):
+            t = (torch.ones(x.shape[0]) * i).long()
+            eps = unet_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, clean=True)
+            if cfg_scale > 0:
+                eps = torch.lerp(unet_forward(sd, x, t, clean=True), eps, cfg_scale)
+            alpha = alphas[t][:, None, None, None]
+            beta = betas[t][:, None, None, None]
+            ah = alpha_hat[t][:, None, None, None]
+            if i > 1:
+                noise = noise_fn(i, x)
+                if data_scaled:
+                    noise = noise * 0.005
+            else:
+                noise = torch.zeros_like(x)
             x = (1 / torch.sqrt(alpha)) * (x - ((1 - alpha) / torch.sqrt(1 - ah)) * eps)
             x = x + torch.sqrt(beta) * noise
             if trace is not None and i in trace.get("want", ()):

@@ -29,6 +29,21 @@ ATTN_LEVELS = ((0, 64, 32), (1, 64, 16), (2, 128, 8), (3, 256, 4), (4, 512, 2)) 
 CHAIN_CASES = {"T50": dict(T=50, B=2), "T200": dict(T=200, B=2), "T1000": dict(T=1000, B=1)}
 BETA_MIN, BETA_MAX = 1e-4, 0.02
 
+# The DDPM_clean_application network (src/unet.py) as src/main_ddpm.py:354-369 builds it (planes + 4 seasons) and a
+# label-only one, the only kind its classifier-free guidance can run on (src/diffusion_modules.py:158 passes no planes).
+CLEAN_VARIANTS = {
+    "clean_cond": dict(lsm=True, topo=True, cond=True, num_classes=4),
+    "clean_class": dict(lsm=False, topo=False, cond=False, num_classes=4),
+}
+CLEAN_SCHEDULE_T = (50, 200, 1000)
+CLEAN_ATTN_LEVELS = ((0, 64, 32), (3, 256, 4))
+CLEAN_CHAINS = {
+    "plain": dict(variant="clean_cond", T=50, B=2, scheduler="linear", cfg_scale=0.0, data_scaled=False),
+    "guided": dict(variant="clean_class", T=50, B=2, scheduler="linear", cfg_scale=3.0, data_scaled=True),
+    "guided_small": dict(variant="clean_class", T=50, B=2, scheduler="cosine", cfg_scale=0.3, data_scaled=False),
+}
+CLEAN_CHAIN_CHECKPOINTS = (49, 25, 1)
+
 
 def randn(seed, *shape):
     g = torch.Generator(device="cpu")
@@ -38,7 +53,7 @@ def randn(seed, *shape):
 
 def variant_inputs(variant, batch, size, seed=SEED):
     """Forward-call arguments (x, y, cond_img, lsm_cond, topo_cond) for a model variant."""
-    v = VARIANTS[variant]
+    v = VARIANTS[variant] if variant in VARIANTS else CLEAN_VARIANTS[variant]
     d = synthetic_inputs(batch, size, size, seed=seed, conditional=True)
     return dict(
         x=d["x"],
@@ -65,3 +80,17 @@ def chain_noise_fn(seed):
         return torch.randn(x.shape, generator=g)
 
     return fn
+
+
+def clean_chain_draws(batch, size, seed=SEED + 2):
+    """Start image and per-step noise of a DDPM_clean_application sampling run in the reference's draw order:
+    ``torch.randn((n, 1, size, size))`` (diffusion_modules.py:129), then one ``randn_like`` per step with i > 1 (:172),
+    all from one generator seeded once."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    x = torch.randn((batch, 1, size, size), generator=g)
+
+    def fn(i, x_):
+        return torch.randn(x_.shape, generator=g)
+
+    return x, fn

@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 REF_DIR = os.environ.get("DANRA_REFERENCE_DIR", "/root/reference/DDPM_DANRA_conditional")
+REF_CLEAN_DIR = os.environ.get("DANRA_REFERENCE_CLEAN_DIR", "/root/reference/DDPM_clean_application/src")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 from oracle import torchvision_standin  # noqa: E402
@@ -69,14 +70,97 @@ def gen_noise_image(ref_diffusion):
     save("noise_image", **out)
 
 
+def import_reference_clean():
+    """DDPM_clean_application/src/{unet,diffusion_modules}.py, imported as top-level modules from their directory."""
+    torchvision_standin.install()
+    sys.path.insert(0, REF_CLEAN_DIR)
+    import unet as ref_unet  # noqa: E402
+    import diffusion_modules as ref_diffusion  # noqa: E402
+    return ref_unet, ref_diffusion
+
+
+def build_reference_clean_model(ref_unet, variant, size):
+    v = gs.CLEAN_VARIANTS[variant]
+    enc = ref_unet.Encoder(1, gs.TIME_EMBEDDING, cond_on_lsm=v["lsm"], cond_on_topo=v["topo"], cond_on_img=v["cond"],
+                           cond_img_dim=(1, size, size) if v["cond"] else None, block_layers=[2, 2, 2, 2],
+                           num_classes=v["num_classes"])
+    dec = ref_unet.Decoder(512, 1, gs.TIME_EMBEDDING, 64)
+    model = ref_unet.DiffusionNet(enc, dec)
+    fill_state_dict_(model, gs.SEED)
+    model.eval()
+    return model
+
+
+def gen_clean():
+    """G8: the DDPM_clean_application variant: schedule, attention + feed-forward blocks, forwards, and sampling chains
+    with and without classifier-free guidance, all computed by the reference's own classes."""
+    ref_unet, ref_diffusion = import_reference_clean()
+    contract = {}
+    out = {}
+    for T in gs.CLEAN_SCHEDULE_T:
+        du = ref_diffusion.DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, "cpu", "cosine")
+        out[f"cosine_{T}_betas"] = du.betas.numpy()
+        out[f"cosine_{T}_alphas"] = du.alphas.numpy()
+        out[f"cosine_{T}_alpha_hat"] = du.alpha_hat.numpy()
+    with torch.no_grad():
+        models = {}
+        for variant in gs.CLEAN_VARIANTS:
+            m = build_reference_clean_model(ref_unet, variant, 64)
+            models[variant] = m
+            contract[variant] = {
+                "state_dict": [[k, list(v.shape)] for k, v in m.state_dict().items()],
+                "parameters": [k for k, _ in m.named_parameters()],
+                "n_parameters": sum(p.numel() for p in m.parameters()),
+            }
+        enc = models["clean_cond"].encoder
+        for lvl, C, side in gs.CLEAN_ATTN_LEVELS:
+            out[f"attn{lvl}"] = enc.attention_layers[lvl](gs.randn(100 + lvl, 1, C, side, side)).numpy()
+        f = gs.randn(131, 1, 256, 4, 4)
+        skip = gs.randn(141, 1, 128, 8, 8)
+        out["dec1"] = models["clean_cond"].decoder.residual_layers[1](f, skip, torch.tensor([7])).numpy()
+        t = torch.full((2,), 500, dtype=torch.long)
+        inp = gs.variant_inputs("clean_cond", 2, 64)
+        out["clean_cond_t500"] = models["clean_cond"](inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"],
+                                                      inp["topo_cond"]).numpy()
+        inp = gs.variant_inputs("clean_class", 2, 64)
+        out["clean_class_t500"] = models["clean_class"](inp["x"], t, inp["y"]).numpy()
+        out["clean_class_t500_nolabel"] = models["clean_class"](inp["x"], t).numpy()
+
+        for name, c in gs.CLEAN_CHAINS.items():
+            model = models[c["variant"]]
+            du = ref_diffusion.DiffusionUtils(c["T"], gs.BETA_MIN, gs.BETA_MAX, "cpu", c["scheduler"], img_size=64,
+                                              data_scaled=c["data_scaled"])
+            inp = gs.variant_inputs(c["variant"], c["B"], 64)
+            states = {}
+
+            class Spy(torch.nn.Module):  # records x entering each timestep's first evaluation
+                def forward(self, x, t, *a, **k):
+                    states.setdefault(int(t[0]), x.clone())
+                    return model(x, t, *a, **k)
+
+            torch.manual_seed(gs.SEED + 2)  # the start image (:129) and every randn_like (:172) come from here
+            final = du.sample(c["B"], Spy(), 1, inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"],
+                              topo_cond=inp["topo_cond"], cfg_scale=c["cfg_scale"])
+            for i in gs.CLEAN_CHAIN_CHECKPOINTS:
+                out[f"chain_{name}_x_after_{i}"] = (final if i == 1 else states[i - 1]).numpy()
+    save("clean", **out)
+    with open(os.path.join(GOLDEN, "state_dict_clean.json"), "w") as f:
+        json.dump(contract, f, indent=0)
+    print("wrote state_dict_clean.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the T=1000 chain")
     ap.add_argument("--only-state-dict", action="store_true", help="write only state_dict.json")
     ap.add_argument("--only-noise-image", action="store_true", help="write only noise_image.npz")
+    ap.add_argument("--only-clean", action="store_true", help="write only clean.npz and state_dict_clean.json")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(gs.SEED)
+    if args.only_clean:  # the two reference packages define modules of the same names: one package per run
+        gen_clean()
+        return
     ref_modules, ref_diffusion = import_reference()
 
     if args.only_noise_image:

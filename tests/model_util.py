@@ -22,3 +22,17 @@ def build_model(variant="cond", size=64, seed=gs.SEED):
 
 def state_dict_cpu(model):
     return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def build_clean_model(variant="clean_cond", size=64, seed=gs.SEED):
+    """The DDPM_clean_application network (reference src/main_ddpm.py:354-369), synthetic weights."""
+    from diffusionmodelscustom_amd import unet
+    v = gs.CLEAN_VARIANTS[variant]
+    enc = unet.Encoder(1, gs.TIME_EMBEDDING, cond_on_lsm=v["lsm"], cond_on_topo=v["topo"], cond_on_img=v["cond"],
+                       cond_img_dim=(1, size, size) if v["cond"] else None, block_layers=[2, 2, 2, 2],
+                       num_classes=v["num_classes"])
+    dec = unet.Decoder(512, 1, gs.TIME_EMBEDDING, 64)
+    model = unet.DiffusionNet(enc, dec)
+    fill_state_dict_(model, seed)
+    model.eval()
+    return model

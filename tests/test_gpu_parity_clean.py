@@ -1,0 +1,128 @@
+"""GPU parity tests of the DDPM_clean_application variant (attention blocks with a feed-forward part, classifier-free
+guidance, shrunk noise): the HIP path, called through the C ABI, against the golden vectors captured from the
+reference's own code (tests/golden/clean.npz) and the CPU restatement.  Tolerances as in test_gpu_parity.py."""
+import pytest
+import torch
+
+from conftest import rel_err
+from model_util import build_clean_model, state_dict_cpu
+from oracle import cpu_ref
+from oracle import golden_spec as gs
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-5
+TOL_FWD = 1e-4
+TOL_CHAIN = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def clean(dev):
+    from gpu_util import Ops
+    out = {}
+    for variant in gs.CLEAN_VARIANTS:
+        model = build_clean_model(variant, 64)
+        sd = state_dict_cpu(model)
+        model = model.to(dev)
+        out[variant] = (model, sd, Ops(model.hip_engine(dev)))
+    return out
+
+
+@pytest.mark.parametrize("lvl,C,side", gs.CLEAN_ATTN_LEVELS)
+def test_attention_with_feed_forward(clean, golden, dev, lvl, C, side):
+    _, _, ops = clean["clean_cond"]
+    x = gs.randn(100 + lvl, 1, C, side, side)
+    assert rel_err(ops.attention(lvl, x.to(dev)).cpu(), golden("clean")[f"attn{lvl}"]) < TOL_OP
+
+
+def test_attention_with_feed_forward_every_level_batched(clean, dev):
+    """All nine blocks at batch 3 (L = 1024 ... 4, C = 64 ... 512), the decoder ones with their trailing ReLU,
+    against the restatement."""
+    _, sd, ops = clean["clean_cond"]
+    shapes = [(64, 32), (64, 16), (128, 8), (256, 4), (512, 2), (256, 4), (128, 8), (64, 16), (64, 32)]
+    for idx, (C, side) in enumerate(shapes):
+        x = gs.randn(300 + idx, 3, C, side, side)
+        prefix = f"encoder.attention_layers.{idx}" if idx < 5 else f"decoder.residual_layers.{idx - 5}.attention"
+        want = cpu_ref.image_self_attention_clean(sd, prefix, x)
+        if idx >= 5:
+            want = torch.relu(want)
+        assert rel_err(ops.attention(idx, x.to(dev), relu=idx >= 5).cpu(), want) < TOL_OP, idx
+
+
+def test_decoder_block(clean, golden, dev):
+    _, _, ops = clean["clean_cond"]
+    f, skip = gs.randn(131, 1, 256, 4, 4), gs.randn(141, 1, 128, 8, 8)
+    out = ops.decoder_block(1, f.to(dev), skip.to(dev), torch.tensor([7]).to(dev))
+    assert rel_err(out.cpu(), golden("clean")["dec1"]) < TOL_OP
+
+
+def test_forwards(clean, golden, dev):
+    g = golden("clean")
+    t = torch.full((2,), 500, dtype=torch.long).to(dev)
+    with torch.no_grad():
+        model = clean["clean_cond"][0]
+        inp = {k: None if v is None else v.to(dev) for k, v in gs.variant_inputs("clean_cond", 2, 64).items()}
+        out = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert rel_err(out.cpu(), g["clean_cond_t500"]) < TOL_FWD
+        with pytest.raises(RuntimeError, match="conv1 expects 4 input channels"):
+            model(inp["x"], t, inp["y"], inp["cond_img"])
+        model = clean["clean_class"][0]
+        inp = {k: None if v is None else v.to(dev) for k, v in gs.variant_inputs("clean_class", 2, 64).items()}
+        assert rel_err(model(inp["x"], t, inp["y"]).cpu(), g["clean_class_t500"]) < TOL_FWD
+        assert rel_err(model(inp["x"], t).cpu(), g["clean_class_t500_nolabel"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("name", list(gs.CLEAN_CHAINS))
+def test_chains(clean, golden, dev, name):
+    """diffusion_modules.DiffusionUtils.sample on the device (one C call per chain) against the reference's chains:
+    plain, guided (cfg_scale 3, shrunk noise) and guided with a small weight on the cosine schedule."""
+    from diffusionmodelscustom_amd import diffusion_modules as dm
+    g = golden("clean")
+    c = gs.CLEAN_CHAINS[name]
+    model = clean[c["variant"]][0]
+    du = dm.DiffusionUtils(c["T"], gs.BETA_MIN, gs.BETA_MAX, dev, c["scheduler"], img_size=64, data_scaled=c["data_scaled"])
+    inp = gs.variant_inputs(c["variant"], c["B"], 64)
+    x, fn = gs.clean_chain_draws(c["B"], 64)
+    noise = torch.stack([fn(i, x) for i in range(c["T"] - 1, 1, -1)])
+    out = du.sample_with_host_noise(c["B"], model, 1, noise, start_image=x, y=inp["y"], cond_img=inp["cond_img"],
+                                    lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"], cfg_scale=c["cfg_scale"])
+    assert model.training  # reference diffusion_modules.py:182
+    model.eval()
+    assert rel_err(out.cpu(), g[f"chain_{name}_x_after_1"]) < TOL_CHAIN
+
+
+def test_guided_graph_equals_eager_and_philox_runs(clean, dev):
+    """The guided step (two evaluations + lerp + update) replayed from the captured graph equals the eager loop bit
+    for bit; with in-kernel noise the run is reproducible from its seed; guidance on a network with conditioning
+    planes is refused like the reference's second call fails."""
+    from diffusionmodelscustom_amd import diffusion_modules as dm
+    model = clean["clean_class"][0]
+    engine = model.hip_engine(dev)
+    du = dm.DiffusionUtils(20, gs.BETA_MIN, gs.BETA_MAX, dev, "linear", img_size=64)
+    du.noise_seed = 1234
+    inp = gs.variant_inputs("clean_class", 3, 64)
+    x0 = gs.randn(5, 3, 1, 64, 64)
+    du._start_image = x0
+    try:
+        a = du.sample(3, model, 1, y=inp["y"], cfg_scale=2.0)
+        engine.set_graph_mode(False)
+        b = du.sample(3, model, 1, y=inp["y"], cfg_scale=2.0)
+        engine.set_graph_mode(True)
+        c = du.sample(3, model, 1, y=inp["y"], cfg_scale=0.0)
+    finally:
+        du._start_image = None
+        engine.set_graph_mode(True)
+        model.eval()
+    assert torch.isfinite(a).all() and torch.equal(a, b) and not torch.equal(a, c)
+    cond_model = clean["clean_cond"][0]
+    ci = gs.variant_inputs("clean_cond", 2, 64)
+    with pytest.raises(RuntimeError, match="conv1 expects 4 input channels"):
+        du.sample(2, cond_model, 1, y=ci["y"], cond_img=ci["cond_img"], lsm_cond=ci["lsm_cond"], topo_cond=ci["topo_cond"],
+                  cfg_scale=1.0)
+    cond_model.eval()

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from conftest import GOLDEN_DIR, ROOT, rel_err
-from model_util import build_model
+from model_util import build_clean_model, build_model
 from diffusionmodelscustom_amd import DiffusionUtils, hip_engine
 from diffusionmodelscustom_amd.modules_DANRA_conditional import SinusoidalEmbedding
 from oracle import golden_spec as gs
@@ -186,3 +186,64 @@ def test_checkpoint_round_trip_and_training_step(tmp_path):
     loss.backward()
     opt.step()
     assert torch.isfinite(loss) and not torch.equal(before, model.decoder.final_layer.conv.weight)
+
+
+# ---------------------------------------------------------------- DDPM_clean_application call surface
+@pytest.mark.parametrize("variant", list(gs.CLEAN_VARIANTS))
+def test_clean_state_dict_contract(variant):
+    """Keys, order and shapes of unet.DiffusionNet equal the reference's DDPM_clean_application/src/unet.py network."""
+    with open(os.path.join(GOLDEN_DIR, "state_dict_clean.json")) as f:
+        contract = json.load(f)[variant]
+    m = build_clean_model(variant, 64)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == contract["state_dict"]
+    assert [k for k, _ in m.named_parameters()] == contract["parameters"]
+    assert sum(p.numel() for p in m.parameters()) == contract["n_parameters"]
+
+
+def test_clean_modules_match_golden_forward(golden):
+    g = golden("clean")
+    t = torch.full((2,), 500, dtype=torch.long)
+    with torch.no_grad():
+        m = build_clean_model("clean_cond", 64)
+        inp = gs.variant_inputs("clean_cond", 2, 64)
+        out = m(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert rel_err(out, g["clean_cond_t500"]) < 5e-6
+        m = build_clean_model("clean_class", 64)
+        inp = gs.variant_inputs("clean_class", 2, 64)
+        assert rel_err(m(inp["x"], t, inp["y"]), g["clean_class_t500"]) < 5e-6
+        assert rel_err(m(inp["x"], t), g["clean_class_t500_nolabel"]) < 5e-6
+
+
+def test_clean_diffusion_utils_surface_and_guided_chain(golden):
+    """diffusion_modules.DiffusionUtils: cosine schedule bit-exact, noiseImage shrink, and the guided chain (shrunk
+    noise, cfg_scale 3) through the generic CPU loop against the reference's, same draws; train mode restored."""
+    from diffusionmodelscustom_amd import diffusion_modules as dm
+    g = golden("clean")
+    for T in gs.CLEAN_SCHEDULE_T:
+        du = dm.DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, "cpu", "cosine")
+        assert np.array_equal(du.betas.numpy(), g[f"cosine_{T}_betas"])
+        assert np.array_equal(du.alpha_hat.numpy(), g[f"cosine_{T}_alpha_hat"])
+    du = dm.DiffusionUtils()
+    assert (du.n_timesteps, du.img_size, du.data_scaled, du.scheduler) == (1000, 64, False, "linear")
+    with pytest.raises(AssertionError, match="x must be a 4D tensor but is 3D tensor"):
+        du.noiseImage(torch.zeros(1, 8, 8), torch.tensor([1]))
+    small = dm.DiffusionUtils(50, gs.BETA_MIN, gs.BETA_MAX, "cpu", "linear", img_size=8, data_scaled=True)
+    torch.manual_seed(3)
+    _, noise = small.noiseImage(torch.zeros(4, 1, 8, 8), torch.tensor([1, 5, 20, 49]))
+    torch.manual_seed(3)
+    assert torch.equal(noise, torch.randn(4, 1, 8, 8) * 0.005)
+
+    c = gs.CLEAN_CHAINS["guided"]
+    m = build_clean_model(c["variant"], 64)
+    du = dm.DiffusionUtils(c["T"], gs.BETA_MIN, gs.BETA_MAX, "cpu", c["scheduler"], img_size=64, data_scaled=c["data_scaled"])
+    inp = gs.variant_inputs(c["variant"], c["B"], 64)
+    x, fn = gs.clean_chain_draws(c["B"], 64)
+    noise = torch.stack([fn(i, x) for i in range(c["T"] - 1, 1, -1)])
+    out = du.sample_with_host_noise(c["B"], m, 1, noise, start_image=x, y=inp["y"], cfg_scale=c["cfg_scale"])
+    assert rel_err(out, g["chain_guided_x_after_1"]) < 1e-4
+    assert m.training  # reference diffusion_modules.py:182
+    # without the hooks the start image and the draws come from torch's generator, in the reference's order
+    torch.manual_seed(gs.SEED + 2)
+    m.eval()
+    out2 = du.sample(c["B"], m, 1, y=inp["y"], cfg_scale=c["cfg_scale"])
+    assert rel_err(out2, g["chain_guided_x_after_1"]) < 1e-4

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import rel_err
-from model_util import build_model, state_dict_cpu
+from model_util import build_clean_model, build_model, state_dict_cpu
 from oracle import cpu_ref
 from oracle import golden_spec as gs
 
@@ -129,3 +129,55 @@ def test_noise_image_bit_exact(golden, sched):
     t = torch.from_numpy(g["t"])
     got = cpu_ref.noise_image(x, t, alpha_hat, torch.from_numpy(g[f"{sched}_noise"]))
     assert np.array_equal(got.numpy(), g[f"{sched}_noisy"])
+
+
+# ---------------------------------------------------------------- DDPM_clean_application variant (clean.npz)
+@pytest.fixture(scope="module")
+def sd_clean():
+    return {v: state_dict_cpu(build_clean_model(v, 64)) for v in gs.CLEAN_VARIANTS}
+
+
+@pytest.mark.parametrize("T", gs.CLEAN_SCHEDULE_T)
+def test_clean_cosine_schedule_bit_exact(golden, T):
+    g = golden("clean")
+    betas = cpu_ref.beta_schedule_clean(T, gs.BETA_MIN, gs.BETA_MAX, "cosine")
+    alphas = 1 - betas
+    assert np.array_equal(betas.numpy(), g[f"cosine_{T}_betas"])
+    assert np.array_equal(alphas.numpy(), g[f"cosine_{T}_alphas"])
+    assert np.array_equal(torch.cumprod(alphas, dim=0).numpy(), g[f"cosine_{T}_alpha_hat"])
+
+
+def test_clean_attention_with_feed_forward_and_forwards(golden, sd_clean):
+    g = golden("clean")
+    sd = sd_clean["clean_cond"]
+    with torch.no_grad():
+        for lvl, C, side in gs.CLEAN_ATTN_LEVELS:
+            out = cpu_ref.image_self_attention_clean(sd, f"encoder.attention_layers.{lvl}", gs.randn(100 + lvl, 1, C, side, side))
+            assert rel_err(out, g[f"attn{lvl}"]) < 2e-6, lvl
+        out = cpu_ref.decoder_block(sd, "decoder.residual_layers.1", gs.randn(131, 1, 256, 4, 4), gs.randn(141, 1, 128, 8, 8),
+                                    torch.tensor([7]), clean=True)
+        assert rel_err(out, g["dec1"]) < 2e-6
+        t = torch.full((2,), 500, dtype=torch.long)
+        inp = gs.variant_inputs("clean_cond", 2, 64)
+        out = cpu_ref.unet_forward(sd, inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"], clean=True)
+        assert rel_err(out, g["clean_cond_t500"]) < 5e-6
+        inp = gs.variant_inputs("clean_class", 2, 64)
+        sd = sd_clean["clean_class"]
+        assert rel_err(cpu_ref.unet_forward(sd, inp["x"], t, inp["y"], clean=True), g["clean_class_t500"]) < 5e-6
+        assert rel_err(cpu_ref.unet_forward(sd, inp["x"], t, clean=True), g["clean_class_t500_nolabel"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", list(gs.CLEAN_CHAINS))
+def test_clean_chains(golden, sd_clean, name):
+    """Sampling chains of the clean variant (plain, guided with shrunk noise, guided with a small weight on the cosine
+    schedule) against the reference's, same draws."""
+    g = golden("clean")
+    c = gs.CLEAN_CHAINS[name]
+    inp = gs.variant_inputs(c["variant"], c["B"], 64)
+    x, fn = gs.clean_chain_draws(c["B"], 64)
+    trace = {"want": set(gs.CLEAN_CHAIN_CHECKPOINTS)}
+    cpu_ref.sample_clean(sd_clean[c["variant"]], x, c["T"], gs.BETA_MIN, gs.BETA_MAX, inp["y"], inp["cond_img"],
+                         inp["lsm_cond"], inp["topo_cond"], scheduler=c["scheduler"], cfg_scale=c["cfg_scale"],
+                         data_scaled=c["data_scaled"], noise_fn=fn, trace=trace)
+    for i in gs.CLEAN_CHAIN_CHECKPOINTS:
+        assert rel_err(trace[i], g[f"chain_{name}_x_after_{i}"]) < 1e-4, i
