@@ -33,17 +33,23 @@ WORKLOADS = {
     "c3": dict(name="DANRA conditional (lsm+topo+cond image+season embedding) 64x64, T=1000, batch 64/GPU", size=64,
                batch=64, cond=True),
     "c4": dict(name="DANRA conditional 128x128, T=1000, batch 32/GPU", size=128, batch=32, cond=True),
+    # the DDPM_clean_application variant (attention blocks with a feed-forward part); not BASELINE configs
+    "clean": dict(name="clean-application network, conditional (lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU",
+                  size=64, batch=64, cond=True, clean=True),
+    "clean_cfg": dict(name="clean-application network, season label only, classifier-free guidance 3.0 (two UNet "
+                           "evaluations per step) 64x64, T=1000, batch 64/GPU", size=64, batch=64, cond=False, clean=True,
+                      labels=True, cfg_scale=3.0),
 }
 
 
-def unet_flops_per_image(size, in_ch):
+def unet_flops_per_image(size, in_ch, attn_ff=False):
     """2 x multiply-adds of every convolution, linear and attention product of one UNet evaluation
     (norms, activations and the softmax itself excluded)."""
     fl = 0.0
     s2, s4 = size // 2, size // 4
 
     def attn(L, C):
-        return 2.0 * L * C * 3 * C + 4.0 * L * L * C + 2.0 * L * C * C
+        return 2.0 * L * C * 3 * C + 4.0 * L * L * C + 2.0 * L * C * C + (4.0 * L * C * C if attn_ff else 0.0)
 
     fl += 2.0 * s2 * s2 * 64 * 64 * in_ch            # conv1 8x8
     fl += attn(s2 * s2, 64)
@@ -84,6 +90,12 @@ def flash_traffic_per_launch(workload, batch):
 
 def build_model(w, seed):
     size = w["size"]
+    if w.get("clean"):
+        from diffusionmodelscustom_amd import unet
+        enc = unet.Encoder(1, 256, cond_on_lsm=w["cond"], cond_on_topo=w["cond"], cond_on_img=w["cond"],
+                           cond_img_dim=(1, size, size) if w["cond"] else None, block_layers=[2, 2, 2, 2],
+                           num_classes=4 if (w["cond"] or w.get("labels")) else None)
+        return fill_state_dict_(unet.DiffusionNet(enc, unet.Decoder(512, 1, 256, 64)), seed).eval()
     if w["cond"]:
         enc = Encoder(1, 256, lsm_tensor=torch.zeros(1, size, size), topo_tensor=torch.zeros(1, size, size),
                       cond_on_img=True, cond_img_dim=(1, size, size), block_layers=[2, 2, 2, 2], num_classes=4)
@@ -91,6 +103,13 @@ def build_model(w, seed):
         enc = Encoder(1, 256, block_layers=[2, 2, 2, 2])
     model = DiffusionNet(enc, Decoder(512, 1, 256, 64))
     return fill_state_dict_(model, seed).eval()
+
+
+def workload_inputs(w, batch, seed):
+    inp = synthetic_inputs(batch, w["size"], w["size"], seed=seed, conditional=w["cond"] or bool(w.get("labels")))
+    if not w["cond"]:
+        inp.update(cond_img=None, lsm_cond=None, topo_cond=None)
+    return inp
 
 
 def cpu_baseline(w, n_steps=25, batch=None):
@@ -101,7 +120,8 @@ def cpu_baseline(w, n_steps=25, batch=None):
     batch = batch or w["batch"]
     model = build_model(w, 42)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    inp = synthetic_inputs(batch, w["size"], w["size"], seed=42, conditional=w["cond"])
+    inp = workload_inputs(w, batch, 42)
+    clean, guide = bool(w.get("clean")), float(w.get("cfg_scale", 0.0))
     betas, alphas, alpha_hat = cpu_ref.schedule(1000, 1e-4, 0.02)
     x = inp["x"]
     times = []
@@ -109,7 +129,9 @@ def cpu_baseline(w, n_steps=25, batch=None):
         for k, i in enumerate(range(999, 999 - (n_steps + 1), -1)):
             t0 = time.perf_counter()
             t = torch.full((batch,), i, dtype=torch.long)
-            eps = cpu_ref.unet_forward(sd, x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+            eps = cpu_ref.unet_forward(sd, x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"], clean=clean)
+            if guide > 0:
+                eps = torch.lerp(cpu_ref.unet_forward(sd, x, t, clean=clean), eps, guide)
             c1, c2, c3 = cpu_ref.update_coefficients(betas, alphas, alpha_hat, i)
             x = cpu_ref.ddpm_update(x, eps, torch.randn_like(x), c1, c2, c3)
             if k:
@@ -155,13 +177,22 @@ def main():
     # rank 0 holds the weights; the other ranks start from a different fill and receive them by broadcast
     model = build_model(w, 42 if rank == 0 else 1000 + rank).to(dev)
     sent = broadcast_model_(model, src=0)
-    inp = synthetic_inputs(B, w["size"], w["size"], seed=42 + rank, conditional=w["cond"])
+    inp = workload_inputs(w, B, 42 + rank)
     inp = {k: (None if v is None else v.to(dev)) for k, v in inp.items()}
-    du = DiffusionUtils(T, 1e-4, 0.02, dev, "linear")
+    if w.get("clean"):
+        from diffusionmodelscustom_amd.diffusion_modules import DiffusionUtils as CleanDiffusionUtils
+        du = CleanDiffusionUtils(T, 1e-4, 0.02, dev, "linear", img_size=w["size"])
+    else:
+        du = DiffusionUtils(T, 1e-4, 0.02, dev, "linear")
     du.noise_seed = 42 + rank
     engine = model.hip_engine(dev)
 
     def one_step():
+        if w.get("clean"):  # draws its own start image on the host, as the reference does
+            out = du.sample(B, model, 1, y=inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"],
+                            topo_cond=inp["topo_cond"], cfg_scale=w.get("cfg_scale", 0.0))
+            model.eval()
+            return out
         return du.sample(inp["x"], model, inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"],
                          topo_cond=inp["topo_cond"])
 
@@ -192,7 +223,7 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         in_ch = 4 if w["cond"] else 1
-        fl_img = unet_flops_per_image(w["size"], in_ch)
+        fl_img = unet_flops_per_image(w["size"], in_ch, bool(w.get("clean"))) * (2 if w.get("cfg_scale", 0.0) > 0 else 1)
         value = images / elapsed
         achieved = (kern_flops / (kern_ms * 1e-3) / 1e12) if kern_ms > 0 else None
         line = {
@@ -212,7 +243,7 @@ def main():
                        "image": f"{w['size']}x{w['size']}", "parallelism": f"batch-sharded x{world}, weights broadcast "
                        f"once ({sent} bytes), no collective in the loop"},
             "unet_ms": 1e3 * elapsed / args.steps / (T - 1),
-            "flops_per_image_per_unet_eval": fl_img,
+            "flops_per_image_per_denoise_step": fl_img,
             "whole_path_tflops": value * (T - 1) * fl_img / 1e12 / world,
             "whole_path_frac_of_fp32_peak": value * (T - 1) * fl_img / 1e12 / world / FP32_MATRIX_PEAK_TFLOPS,
             "roofline": {
