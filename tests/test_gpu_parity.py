@@ -487,3 +487,31 @@ def test_batch_larger_than_the_benchmark(cond64, dev):
             one = model(inp["x"][i:i + 1], t[i:i + 1], inp["y"][i:i + 1], inp["cond_img"][i:i + 1],
                         inp["lsm_cond"][i:i + 1], inp["topo_cond"][i:i + 1])
             assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
+
+
+def test_forward_and_chain_on_the_reference_shipped_inputs(cond64, golden, dev):
+    """Real conditioning data: ERA5 conditioning images (with their -273.15 fill values), fractional land-sea masks and season
+    labels cut from the sample files the reference ships (tests/golden/real_inputs.npz), synthetic topography.
+    One forward and a 12-step chain against the restatement."""
+    model, sd, _ = cond64
+    g = golden("real_inputs")
+    cond, lsm = torch.from_numpy(g["cond"]), torch.from_numpy(g["lsm"])
+    y = torch.from_numpy(g["season"])
+    assert float(cond.min()) < -200.0 and 0.0 <= float(lsm.min()) and float(lsm.max()) <= 1.0 and int(y.max()) <= 3
+    topo = gs.variant_inputs("cond", 8, 64)["topo_cond"]
+    x = gs.randn(77, 8, 1, 64, 64)
+    t = torch.tensor([999, 700, 500, 300, 100, 10, 2, 1])
+    with torch.no_grad():
+        want = cpu_ref.unet_forward(sd, x, t, y, cond, lsm, topo)
+        got = model(x.to(dev), t.to(dev), y.to(dev), cond.to(dev), lsm.to(dev), topo.to(dev))
+    assert rel_err(got.cpu(), want) < TOL_FWD
+    from diffusionmodelscustom_amd import DiffusionUtils
+    T = 13
+    fn = gs.chain_noise_fn(5)
+    noise = torch.stack([fn(i, x) for i in range(T - 1, 1, -1)])
+    fn = gs.chain_noise_fn(5)
+    want = cpu_ref.sample(sd, x, T, gs.BETA_MIN, gs.BETA_MAX, y, cond, lsm, topo, noise_fn=fn)
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    got = du.sample_with_host_noise(x.to(dev), model, noise, y.to(dev), cond_img=cond.to(dev), lsm_cond=lsm.to(dev),
+                                    topo_cond=topo.to(dev))
+    assert rel_err(got.cpu(), want) < TOL_CHAIN

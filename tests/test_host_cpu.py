@@ -247,3 +247,33 @@ def test_clean_diffusion_utils_surface_and_guided_chain(golden):
     m.eval()
     out2 = du.sample(c["B"], m, 1, y=inp["y"], cfg_scale=c["cfg_scale"])
     assert rel_err(out2, g["chain_guided_x_after_1"]) < 1e-4
+
+
+def test_generation_files_have_the_reference_layout(tmp_path):
+    """The six .npz files of a generation run (next row f3) carry the same key, dtype and per-sample shape as the files
+    the reference ships (final_generated_samples/, metadata in tests/golden/generation_files.json), and load back."""
+    from diffusionmodelscustom_amd import generation_io as gio
+    with open(os.path.join(GOLDEN_DIR, "generation_files.json")) as f:
+        ref = json.load(f)
+    n = 5
+    name = gio.save_name("DDPM_conditional_ERA5", "temp", "64x64", "ERA5_cond_lsm_topo_random__simple__4_seasons_"
+                         "ValidSplitInTime_9yrs", 100)
+    assert name == ref["run"]
+    gen = torch.randn(n, 1, 64, 64)
+    season = torch.randint(0, 4, (n,))
+    point = torch.randint(0, 500, (4, n))
+    paths = gio.save_generation_samples(str(tmp_path), name, gen, gen + 1, torch.ones_like(gen), gen * 2, season, point)
+    for kind, meta in ref["files"].items():
+        assert os.path.basename(paths[kind]) == f"{kind}_samples__{ref['run']}"
+        with np.load(paths[kind], allow_pickle=False) as z:
+            assert z.files == list(meta)
+            shape, dtype = meta["arr_0"]
+            got = z["arr_0"]
+            assert str(got.dtype) == dtype and got.ndim == len(shape)
+            assert list(got.shape) == [n if d == 100 else d for d in shape]
+    back = gio.load_generation_samples(str(tmp_path), name)
+    assert np.array_equal(back["gen"], gen.numpy()) and np.array_equal(back["season"], season.numpy())
+    # an unconditional run saves None for what it does not use; nothing is unpickled on the way back
+    gio.save_generation_samples(str(tmp_path), "u.npz", gen)
+    back = gio.load_generation_samples(str(tmp_path), "u.npz")
+    assert back["cond"] is None and back["season"] is None and np.array_equal(back["gen"], gen.numpy())
