@@ -36,6 +36,9 @@ WORKLOADS = {
     # the DDPM_clean_application variant (attention blocks with a feed-forward part); not BASELINE configs
     "clean": dict(name="clean-application network, conditional (lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU",
                   size=64, batch=64, cond=True, clean=True),
+    "clean_h1": dict(name="clean-application network with its configuration default of 1 attention head, conditional "
+                          "(lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU", size=64, batch=64, cond=True,
+                     clean=True, heads=1),
     "clean_cfg": dict(name="clean-application network, season label only, classifier-free guidance 3.0 (two UNet "
                            "evaluations per step) 64x64, T=1000, batch 64/GPU", size=64, batch=64, cond=False, clean=True,
                       labels=True, cfg_scale=3.0),
@@ -94,8 +97,9 @@ def build_model(w, seed):
         from diffusionmodelscustom_amd import unet
         enc = unet.Encoder(1, 256, cond_on_lsm=w["cond"], cond_on_topo=w["cond"], cond_on_img=w["cond"],
                            cond_img_dim=(1, size, size) if w["cond"] else None, block_layers=[2, 2, 2, 2],
-                           num_classes=4 if (w["cond"] or w.get("labels")) else None)
-        return fill_state_dict_(unet.DiffusionNet(enc, unet.Decoder(512, 1, 256, 64)), seed).eval()
+                           num_classes=4 if (w["cond"] or w.get("labels")) else None, n_heads=w.get("heads", 4))
+        dec = unet.Decoder(512, 1, 256, 64, n_heads=w.get("heads", 4))
+        return fill_state_dict_(unet.DiffusionNet(enc, dec), seed).eval()
     if w["cond"]:
         enc = Encoder(1, 256, lsm_tensor=torch.zeros(1, size, size), topo_tensor=torch.zeros(1, size, size),
                       cond_on_img=True, cond_img_dim=(1, size, size), block_layers=[2, 2, 2, 2], num_classes=4)
@@ -129,9 +133,11 @@ def cpu_baseline(w, n_steps=25, batch=None):
         for k, i in enumerate(range(999, 999 - (n_steps + 1), -1)):
             t0 = time.perf_counter()
             t = torch.full((batch,), i, dtype=torch.long)
-            eps = cpu_ref.unet_forward(sd, x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"], clean=clean)
+            heads = w.get("heads", 4)
+            eps = cpu_ref.unet_forward(sd, x, t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"], clean=clean,
+                                       n_heads=heads)
             if guide > 0:
-                eps = torch.lerp(cpu_ref.unet_forward(sd, x, t, clean=clean), eps, guide)
+                eps = torch.lerp(cpu_ref.unet_forward(sd, x, t, clean=clean, n_heads=heads), eps, guide)
             c1, c2, c3 = cpu_ref.update_coefficients(betas, alphas, alpha_hat, i)
             x = cpu_ref.ddpm_update(x, eps, torch.randn_like(x), c1, c2, c3)
             if k:

@@ -732,7 +732,8 @@ int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
     if (!cfg || !out) return fail(DANRA_EINVAL, "null argument");
     if (cfg->time_embedding <= 0 || cfg->time_embedding % 8 || cfg->time_embedding > 512)
         return fail(DANRA_EINVAL, "time_embedding=%d must be a multiple of 8 and <= 512", cfg->time_embedding);
-    if (cfg->n_heads != 4) return fail(DANRA_EINVAL, "n_heads=%d unsupported (4 only)", cfg->n_heads);
+    if (cfg->n_heads != 1 && cfg->n_heads != 2 && cfg->n_heads != 4 && cfg->n_heads != 8)
+        return fail(DANRA_EINVAL, "n_heads=%d unsupported (1, 2, 4 or 8)", cfg->n_heads);
     if (cfg->out_channels < 1 || cfg->out_channels > 4) return fail(DANRA_EINVAL, "out_channels must be 1..4");
     for (int i = 0; i < 4; ++i)
         if (cfg->block_layers[i] < 1 || cfg->block_layers[i] > 8) return fail(DANRA_EINVAL, "block_layers out of range");

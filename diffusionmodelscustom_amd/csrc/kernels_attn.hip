@@ -9,6 +9,8 @@
 // k_attn_reg: the deeper levels (L <= 256 tokens, head_dim 32 / 64 / 128): one wave per 16-query tile, all
 // score tiles in registers, exact two-pass softmax, operands read straight from memory.
 //
+// k_flash_wide: the flash scheme for head_dim 32 / 64 and L a multiple of 128 (networks with 2 heads or 1 head).
+//
 // k_attn_small: fallback for any other shape (plain VALU, keys walked in LDS chunks with online softmax).
 #include "danra_kernels.h"
 
@@ -207,6 +209,282 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_flash_wide<DT>: the same flash scheme for head_dim = 16*DT (32 or 64: networks built with 2 heads or 1 head
+// at the 64-channel levels) and L a multiple of 128.  Per 16-key x 16-query score tile it issues 4*DT QK^T and
+// 4*DT PV matrix instructions for the same four exponentials per lane, so the softmax arithmetic weighs 1/DT of
+// what it does at head_dim 16.  Operand mapping: MFMA step s of QK^T consumes d = (HD/4)*g + s from both K and Q
+// (lane (row, g) reads HD/4 consecutive floats of its row); PV walks the DT 16-wide slices of V.
+template <int DT, int QT>  // QT = 16-query tiles per wave (a workgroup owns 64*QT queries)
+__global__ __launch_bounds__(256) void k_flash_wide(const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, float* __restrict__ O, int L,
+                                                    int heads, int n_bh, float scale_log2e) {
+    constexpr int HD = 16 * DT;
+    constexpr int HQ = 4 * DT;       // floats of a row per lane in QK^T
+    constexpr int ROW = HD + 4;      // padded LDS row
+    constexpr int PER = KVT * HD / 4 / 256;  // float4 per thread and operand of a 64-key tile
+    extern __shared__ __attribute__((aligned(16))) float fw_s[];
+    float* Ks = fw_s;                        // [2][KVT * ROW]
+    float* Vs = fw_s + 2 * KVT * ROW;        // [2][KVT * ROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = L / (4 * QT * 16);
+    int bh, qblk;
+    if (n_bh % 8 == 0) {  // all query blocks of one (image, head) on one XCD, as in k_flash_hd16
+        const int id = blockIdx.x;
+        bh = (id / (8 * nq)) * 8 + (id & 7);
+        qblk = (id >> 3) % nq;
+    } else {
+        bh = blockIdx.x / nq;
+        qblk = blockIdx.x - bh * nq;
+    }
+    const int q0 = qblk * (4 * QT * 16) + wave * (QT * 16);
+    const int lq = lane & 15;
+    const int g = lane >> 4;
+    const float* Qb = Q + (size_t)bh * L * HD;
+    const float* Kb = K + (size_t)bh * L * HD;
+    const float* Vb = V + (size_t)bh * L * HD;
+
+    float qf[QT][HQ];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * HD + HQ * g + 4 * j);
+            qf[t][4 * j] = v.x * scale_log2e; qf[t][4 * j + 1] = v.y * scale_log2e;
+            qf[t][4 * j + 2] = v.z * scale_log2e; qf[t][4 * j + 3] = v.w * scale_log2e;
+        }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 ot[QT][DT], negm[QT];
+    f32x2 lrun[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lrun[t] = f32x2{0.f, 0.f};
+    }
+    // staging: thread owns float4 number tid + 256*i of the tile (row = idx / (HD/4), column quad = idx % (HD/4))
+    float4 kreg[PER], vreg[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i;
+        kreg[i] = reinterpret_cast<const float4*>(Kb)[idx];
+        vreg[i] = reinterpret_cast<const float4*>(Vb)[idx];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, r = idx / (HD / 4), c4 = (idx - r * (HD / 4)) * 4;
+        *reinterpret_cast<float4*>(Ks + r * ROW + c4) = kreg[i];
+        *reinterpret_cast<float4*>(Vs + r * ROW + c4) = vreg[i];
+    }
+    __syncthreads();
+
+    const int ntiles = L / KVT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        const float* Kt = Ks + buf * KVT * ROW;
+        const float* Vt = Vs + buf * KVT * ROW;
+        {
+            const int nxt = min(kt + 1, ntiles - 1);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + 256 * i;
+                kreg[i] = reinterpret_cast<const float4*>(Kb + (size_t)nxt * KVT * HD)[idx];
+                vreg[i] = reinterpret_cast<const float4*>(Vb + (size_t)nxt * KVT * HD)[idx];
+            }
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 s[QT][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float kf[HQ];
+#pragma unroll
+                for (int u = 0; u < DT; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(Kt + ((2 * hf + j) * 16 + lq) * ROW + HQ * g + 4 * u);
+                    kf[4 * u] = v.x; kf[4 * u + 1] = v.y; kf[4 * u + 2] = v.z; kf[4 * u + 3] = v.w;
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 a = negm[t];
+#pragma unroll
+                    for (int u = 0; u < HQ; ++u) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u], qf[t][u], a, 0, 0, 0);
+                    s[t][j] = a;
+                }
+            }
+            float mx[QT];
+            const bool first = (kt == 0 && hf == 0);
+            bool move = first;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float m0 = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
+                const float m1 = max3f(s[t][0][3], s[t][1][0], s[t][1][1]);
+                const float m2 = max3f(s[t][1][2], s[t][1][3], m0);
+                mx[t] = fmaxf(m1, m2);
+                move = move || (mx[t] > RESCALE_LOG2);
+            }
+            if (__any(move)) {
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    float m = mx[t];
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    const float delta = first ? m : ((m > RESCALE_LOG2) ? m : 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) negm[t][r] -= delta;
+                    lrun[t] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ot[t][dt][r] *= alpha;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[t][j][r] -= delta;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[t][j][0]);
+                    const float p1 = __builtin_amdgcn_exp2f(s[t][j][1]);
+                    const float p2 = __builtin_amdgcn_exp2f(s[t][j][2]);
+                    const float p3 = __builtin_amdgcn_exp2f(s[t][j][3]);
+                    s[t][j] = f32x4{p0, p1, p2, p3};
+                    lrun[t] += f32x2{p0, p1};
+                    lrun[t] += f32x2{p2, p3};
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    float vf[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vf[r] = Vt[((2 * hf + j) * 16 + 4 * g + r) * ROW + 16 * dt + lq];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ot[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], s[t][j][r], ot[t][dt], 0, 0, 0);
+                }
+        }
+        {
+            float* Kn = Ks + (buf ^ 1) * KVT * ROW;
+            float* Vn = Vs + (buf ^ 1) * KVT * ROW;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + 256 * i, r = idx / (HD / 4), c4 = (idx - r * (HD / 4)) * 4;
+                *reinterpret_cast<float4*>(Kn + r * ROW + c4) = kreg[i];
+                *reinterpret_cast<float4*>(Vn + r * ROW + c4) = vreg[i];
+            }
+            __syncthreads();
+        }
+    }
+    const int b = bh / heads, head = bh - b * heads;
+    const int C = heads * HD;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = lrun[t][0] + lrun[t][1];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        float* dst = O + ((size_t)b * L + q0 + t * 16 + lq) * C + head * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<float4*>(dst + 16 * dt) =
+                make_float4(ot[t][dt][0] * inv, ot[t][dt][1] * inv, ot[t][dt][2] * inv, ot[t][dt][3] * inv);
+    }
+}
+
+template <int DT, int QT>
+static hipError_t launch_flash_wide_qt(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                                       hipStream_t stream) {
+    constexpr int HD = 16 * DT;
+    const size_t lds = (size_t)4 * KVT * (HD + 4) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_flash_wide<DT, QT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const float scale_log2e = (1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
+    hipLaunchKernelGGL((k_flash_wide<DT, QT>), dim3((L / (64 * QT)) * B * heads), dim3(256), lds, stream, q, k, v, out, L,
+                       heads, B * heads, scale_log2e);
+    return hipGetLastError();
+}
+// L must be a multiple of 64.  Workgroups of 128 queries when that still gives every CU two of them, else 64.
+template <int DT>
+static hipError_t launch_flash_wide(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                                    hipStream_t stream) {
+    if (L % 128 == 0 && (long)(L / 128) * B * heads >= 512) return launch_flash_wide_qt<DT, 2>(q, k, v, out, B, heads, L, stream);
+    return launch_flash_wide_qt<DT, 1>(q, k, v, out, B, heads, L, stream);
+}
+
+// Very short sequences (L <= 16 tokens: the deepest levels) with a wide head (any head_dim): one workgroup per
+// (image, head), one wave per query.  A lane owns head_dim/64 strided columns: the L dot products are reduced across
+// the wave, the softmax over the L scores is wave-uniform, and each lane forms its own output columns.
+template <int NC, int ML>  // head_dim <= 64 * NC, L <= ML <= 16
+__global__ __launch_bounds__(64 * ML) void k_attn_tiny(const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, float* __restrict__ O, int L,
+                                                    int hd, int heads, float scale) {
+    const int lane = threadIdx.x & 63, qi = threadIdx.x >> 6;
+    const int bh = blockIdx.x;
+    if (qi >= L) return;
+    const float* Qr = Q + ((size_t)bh * L + qi) * hd;
+    const float* Kb = K + (size_t)bh * L * hd;
+    const float* Vb = V + (size_t)bh * L * hd;
+    // Every load is unconditional (indices clamped, contributions zeroed instead): a load under a condition becomes
+    // a branch with its own wait, and the ~100 loads of a wave would then be served one after the other.
+    int dcol[NC];
+    float qv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        dcol[c] = min(lane + 64 * c, hd - 1);
+        const float v = Qr[dcol[c]];
+        qv[c] = (lane + 64 * c < hd) ? v : 0.f;
+    }
+    float sc[ML];
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+        const float* krow = Kb + (size_t)min(j, L - 1) * hd;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a = fmaf(qv[c], krow[dcol[c]], a);
+        sc[j] = a;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+        float a = sc[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        sc[j] = (j < L) ? a * scale : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+        sc[j] = (j < L) ? expf(sc[j] - mx) : 0.f;
+        sum += sc[j];
+    }
+    const float inv = 1.0f / sum;
+    const int b = bh / heads, head = bh - b * heads;
+    float* dst = O + ((size_t)b * L + qi) * (heads * hd) + head * hd;
+    float o[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {  // sc[j] is 0 for j >= L
+        const float* vrow = Vb + (size_t)min(j, L - 1) * hd;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = fmaf(sc[j], vrow[dcol[c]], o[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (lane + 64 * c < hd) dst[lane + 64 * c] = o[c] * inv;
+}
+
 // Register-resident attention for short sequences (L <= 256) and head_dim = 16*DT: one wave per
 // (batch, head, 16-query tile), no LDS and no barrier.  Same operand trick as k_flash_hd16: the scores
 // are formed transposed (S^T = K Q^T on v_mfma_f32_16x16x4_f32, keys as rows, queries as columns), so a
@@ -319,12 +597,12 @@ static hipError_t launch_attn_reg(const float* q, const float* k, const float* v
     return hipGetLastError();
 }
 
-// Generic fallback for any other shape (any L, head_dim <= 128): grid (B*heads, ceil(L/32)); a workgroup owns 32
-// queries (8 per wave, their running maximum / sum / output in registers) and walks the keys in chunks of 64
-// staged in LDS, with the usual online-softmax rescaling between chunks.  Plain VALU arithmetic: correctness
+// Generic fallback for any other shape (any L, head_dim <= 64*NC <= 512): grid (B*heads, ceil(L/32)); a workgroup
+// owns 32 queries (8 per wave, their running maximum / sum / output in registers) and walks the keys in chunks of
+// AS_KC staged in LDS, with the usual online-softmax rescaling between chunks.  Plain VALU arithmetic: correctness
 // first, this path is not on any benchmarked configuration.
-constexpr int AS_KC = 64;   // keys per chunk
 constexpr int AS_QPW = 8;   // queries per wave
+template <int NC, int AS_KC>  // NC: output columns per lane (head_dim <= 64*NC); AS_KC: keys per chunk (<= 64)
 __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O, int L,
                                                     int hd, int heads, float scale) {
@@ -346,9 +624,13 @@ __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q,
         const int qi = i / hd, d = i - qi * hd;
         Qw[i] = Qb[(size_t)min(q0 + qi, L - 1) * hd + d] * scale;
     }
-    float m[AS_QPW], l[AS_QPW], o0[AS_QPW], o1[AS_QPW];  // lane holds output columns lane and lane + 64
+    float m[AS_QPW], l[AS_QPW], o[AS_QPW][NC];  // lane holds output columns lane + 64*c
 #pragma unroll
-    for (int qi = 0; qi < AS_QPW; ++qi) { m[qi] = -INFINITY; l[qi] = 0.f; o0[qi] = 0.f; o1[qi] = 0.f; }
+    for (int qi = 0; qi < AS_QPW; ++qi) {
+        m[qi] = -INFINITY; l[qi] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[qi][c] = 0.f;
+    }
     for (int k0 = 0; k0 < L; k0 += AS_KC) {
         const int nk = min(AS_KC, L - k0);
         __syncthreads();  // the previous chunk has been consumed (and Qw is written, the first time round)
@@ -376,16 +658,19 @@ __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q,
             for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
             l[qi] = l[qi] * alpha + ps;
             m[qi] = mn;
-            Pw[lane] = pe;
+            if (lane < AS_KC) Pw[lane] = pe;
             __builtin_amdgcn_wave_barrier();
-            float a0 = 0.f, a1 = 0.f;
+            float a[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) a[c] = 0.f;
             for (int j = 0; j < nk; ++j) {
                 const float pj = Pw[j];
-                if (lane < hd) a0 = fmaf(pj, Vs[j * hd + lane], a0);
-                if (lane + 64 < hd) a1 = fmaf(pj, Vs[j * hd + lane + 64], a1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (lane + 64 * c < hd) a[c] = fmaf(pj, Vs[j * hd + lane + 64 * c], a[c]);
             }
-            o0[qi] = o0[qi] * alpha + a0;
-            o1[qi] = o1[qi] * alpha + a1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) o[qi][c] = o[qi][c] * alpha + a[c];
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -397,9 +682,25 @@ __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ Q,
         if (q >= L) continue;
         const float inv = 1.0f / l[qi];
         float* dst = O + ((size_t)b * L + q) * C + head * hd;
-        if (lane < hd) dst[lane] = o0[qi] * inv;
-        if (lane + 64 < hd) dst[lane + 64] = o1[qi] * inv;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (lane + 64 * c < hd) dst[lane + 64 * c] = o[qi][c] * inv;
     }
+}
+
+template <int NC, int KC>
+static hipError_t launch_attn_small(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                                    int hd, hipStream_t stream) {
+    const size_t lds = ((size_t)KC * (hd + 1) + (size_t)KC * hd + 4 * KC + 4 * AS_QPW * (size_t)hd) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_small<NC, KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(B * heads, (L + 4 * AS_QPW - 1) / (4 * AS_QPW));
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL((k_attn_small<NC, KC>), grid, dim3(256), lds, stream, q, k, v, out, L, hd, heads, scale);
+    return hipGetLastError();
 }
 
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
@@ -410,22 +711,29 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
         hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, B * heads, scale_log2e);
         return hipGetLastError();
     }
+    if (L % 64 == 0 && L >= 256) {
+        if (hd == 32) return launch_flash_wide<2>(q, k, v, out, B, heads, L, stream);
+        if (hd == 64) return launch_flash_wide<4>(q, k, v, out, B, heads, L, stream);
+    }
+    if (L <= 16 && hd > 128) {
+        const float scale = 1.0f / sqrtf((float)hd);
+        const dim3 grid(B * heads), block(64 * L);
+        if (hd <= 256 && L <= 4) hipLaunchKernelGGL((k_attn_tiny<4, 4>), grid, block, 0, stream, q, k, v, out, L, hd, heads, scale);
+        else if (hd <= 256) hipLaunchKernelGGL((k_attn_tiny<4, 16>), grid, block, 0, stream, q, k, v, out, L, hd, heads, scale);
+        else if (hd <= 512 && L <= 4) hipLaunchKernelGGL((k_attn_tiny<8, 4>), grid, block, 0, stream, q, k, v, out, L, hd, heads, scale);
+        else if (hd <= 512) hipLaunchKernelGGL((k_attn_tiny<8, 16>), grid, block, 0, stream, q, k, v, out, L, hd, heads, scale);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (L <= 256) {
         if (hd == 32) return launch_attn_reg<2>(q, k, v, out, B, heads, L, stream);
         if (hd == 64) return launch_attn_reg<4>(q, k, v, out, B, heads, L, stream);
         if (hd == 128) return launch_attn_reg<8>(q, k, v, out, B, heads, L, stream);
     }
-    if (hd > 128) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)AS_KC * (hd + 1) + (size_t)AS_KC * hd + 4 * AS_KC + 4 * AS_QPW * (size_t)hd) * sizeof(float);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_small),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    dim3 grid(B * heads, (L + 4 * AS_QPW - 1) / (4 * AS_QPW));
-    const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(k_attn_small, grid, dim3(256), lds, stream, q, k, v, out, L, hd, heads, scale);
-    return hipGetLastError();
+    if (hd <= 128) return launch_attn_small<2, 64>(q, k, v, out, B, heads, L, hd, stream);
+    if (hd <= 256) return launch_attn_small<4, 32>(q, k, v, out, B, heads, L, hd, stream);
+    if (hd <= 512) return launch_attn_small<8, 16>(q, k, v, out, B, heads, L, hd, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace danra

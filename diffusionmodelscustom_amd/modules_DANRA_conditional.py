@@ -264,7 +264,7 @@ class DiffusionNet(nn.Module):
             return False
         g = self.hip_geometry()
         return (e.block is BasicBlock
-                and len(e.block_layers) == 4 and e.n_heads == 4 and d.n_heads == 4
+                and len(e.block_layers) == 4 and e.n_heads in (1, 2, 4, 8) and d.n_heads == e.n_heads
                 and e.time_embedding == d.time_embedding and e.time_embedding % 8 == 0 and e.time_embedding <= 512
                 and d.last_fmap_channels == 512 and d.first_fmap_channels == 64 and 1 <= d.output_channels <= 4
                 and e.conv1.in_channels == 1 + int(g['has_lsm']) + int(g['has_topo']) + int(g['has_cond']))

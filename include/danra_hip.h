@@ -40,7 +40,8 @@ typedef struct {
     int num_classes;     /* 0 = no label embedding */
     int time_embedding;  /* 256 in every driver; must be even and <= 512 */
     int out_channels;    /* Decoder output_channels (1) */
-    int n_heads;         /* 4 */
+    int n_heads;         /* heads of every attention block: 1, 2, 4 or 8 (4 in the DANRA drivers; the clean application's
+                          * configuration default is 1, DDPM_clean_application/config.yaml:51) */
     int block_layers[4]; /* BasicBlocks per ResNet layer ([2,2,2,2]) */
     int attn_ff;         /* 0: the network of DDPM_DANRA_conditional/modules_DANRA_conditional.py.
                           * 1: the network of DDPM_clean_application/src/unet.py: every ImageSelfAttention names its

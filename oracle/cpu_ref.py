@@ -134,8 +134,10 @@ def image_self_attention_clean(sd, prefix, x, n_heads=4):
     return (tok + h).permute(0, 2, 1).reshape(-1, C, H, W)
 
 
-def _attention(sd, prefix, x, clean, faithful=False):
-    return image_self_attention_clean(sd, prefix, x) if clean else image_self_attention(sd, prefix, x, faithful=faithful)
+def _attention(sd, prefix, x, clean, faithful=False, n_heads=4):
+    if clean:
+        return image_self_attention_clean(sd, prefix, x, n_heads)
+    return image_self_attention(sd, prefix, x, n_heads, faithful=faithful)
 
 
 def _bn(sd, prefix, x):
@@ -166,7 +168,8 @@ def resnet_layer(sd, prefix, x, stride):
     return x
 
 
-def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False):
+def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False,
+                    n_heads=4):
     """modules_DANRA_conditional.py:213-312; clean: DDPM_clean_application/src/unet.py:217-316, where lsm/topo are
     concatenated iff passed (:232-239) instead of iff the buffers exist."""
     p = "encoder."
@@ -182,19 +185,19 @@ def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=No
     fmaps = []
     f = F.conv2d(x, sd[p + "conv1.weight"], None, 2, 3)
     f = f + time_projection(sd, p + "time_projection_layers.0", emb)[:, :, None, None]
-    f = _attention(sd, p + "attention_layers.0", f, clean, faithful)
+    f = _attention(sd, p + "attention_layers.0", f, clean, faithful, n_heads)
     fmaps.append(f)
     h = F.conv2d(f, sd[p + "conv2.weight"], None, 2, 3)
     h = F.relu(_bn(sd, p + "bn1", h))
     for lvl in range(1, 5):
         h = resnet_layer(sd, f"{p}layer{lvl}", h, 1 if lvl == 1 else 2)
         h = h + time_projection(sd, f"{p}time_projection_layers.{lvl}", emb)[:, :, None, None]
-        h = _attention(sd, f"{p}attention_layers.{lvl}", h, clean, faithful)
+        h = _attention(sd, f"{p}attention_layers.{lvl}", h, clean, faithful, n_heads)
         fmaps.append(h)
     return tuple(fmaps)
 
 
-def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithful=False, clean=False):
+def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithful=False, clean=False, n_heads=4):
     """modules_DANRA_conditional.py:425-460; ``final`` = the block built at :503-509
     (no second InstanceNorm, no attention, Identity activation)."""
     out = F.conv_transpose2d(fmap, sd[prefix + ".transpose.weight"], sd[prefix + ".transpose.bias"], stride=2)
@@ -208,23 +211,25 @@ def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithfu
     if t is not None:
         emb = decoder_sinusoidal_embedding(t, faithful=faithful)
         out = out + time_projection(sd, prefix + ".time_projection_layer", emb)[:, :, None, None]
-        out = _attention(sd, prefix + ".attention", out, clean, faithful)
+        out = _attention(sd, prefix + ".attention", out, clean, faithful, n_heads)
     return out if final else F.relu(out)
 
 
-def decoder_forward(sd, fmaps, t, faithful=False, clean=False):
+def decoder_forward(sd, fmaps, t, faithful=False, clean=False, n_heads=4):
     """modules_DANRA_conditional.py:512-536 (clean: unet.py:516-540, the same)."""
     fm = list(reversed(fmaps))
-    out = decoder_block(sd, "decoder.residual_layers.0", fm[0], fm[1], t, faithful=faithful, clean=clean)
+    out = decoder_block(sd, "decoder.residual_layers.0", fm[0], fm[1], t, faithful=faithful, clean=clean, n_heads=n_heads)
     for idx in range(1, 4):
-        out = decoder_block(sd, f"decoder.residual_layers.{idx}", out, fm[idx + 1], t, faithful=faithful, clean=clean)
+        out = decoder_block(sd, f"decoder.residual_layers.{idx}", out, fm[idx + 1], t, faithful=faithful, clean=clean,
+                            n_heads=n_heads)
     return decoder_block(sd, "decoder.final_layer", out, final=True)
 
 
-def unet_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False):
+def unet_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None, faithful=False, clean=False,
+                 n_heads=4):
     """DiffusionNet.forward, modules_DANRA_conditional.py:597-616 (clean: unet.py:597-616)."""
-    fmaps = encoder_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, faithful=faithful, clean=clean)
-    return decoder_forward(sd, fmaps, t, faithful=faithful, clean=clean)
+    fmaps = encoder_forward(sd, x, t, y, cond_img, lsm_cond, topo_cond, faithful=faithful, clean=clean, n_heads=n_heads)
+    return decoder_forward(sd, fmaps, t, faithful=faithful, clean=clean, n_heads=n_heads)
 
 
 # --------------------------------------------------------------------------- sampling loop

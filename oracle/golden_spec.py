@@ -43,6 +43,9 @@ CLEAN_CHAINS = {
     "guided_small": dict(variant="clean_class", T=50, B=2, scheduler="cosine", cfg_scale=0.3, data_scaled=False),
 }
 CLEAN_CHAIN_CHECKPOINTS = (49, 25, 1)
+# head counts other than the constructors' default of 4: the clean application's configuration default is 1
+# (DDPM_clean_application/config.yaml:51, test/launch.py:62); 2 and 8 exercise head_dim 32 and 8 at the 64-channel levels
+HEAD_CASES = (("clean_cond", 1), ("clean_class", 2), ("cond", 8))
 
 
 def randn(seed, *shape):

@@ -34,14 +34,14 @@ def import_reference():
     return ref_modules, ref_diffusion
 
 
-def build_reference_model(ref_modules, variant, size):
+def build_reference_model(ref_modules, variant, size, n_heads=4):
     v = gs.VARIANTS[variant]
     lsm = torch.zeros(1, size, size) if v["lsm"] else None
     topo = torch.zeros(1, size, size) if v["topo"] else None
     enc = ref_modules.Encoder(1, gs.TIME_EMBEDDING, lsm_tensor=lsm, topo_tensor=topo,
                               cond_on_img=v["cond"], cond_img_dim=(1, size, size) if v["cond"] else None,
-                              block_layers=[2, 2, 2, 2], num_classes=v["num_classes"])
-    dec = ref_modules.Decoder(512, 1, gs.TIME_EMBEDDING, 64)
+                              block_layers=[2, 2, 2, 2], num_classes=v["num_classes"], n_heads=n_heads)
+    dec = ref_modules.Decoder(512, 1, gs.TIME_EMBEDDING, 64, n_heads=n_heads)
     model = ref_modules.DiffusionNet(enc, dec)
     fill_state_dict_(model, gs.SEED)
     model.eval()
@@ -79,12 +79,12 @@ def import_reference_clean():
     return ref_unet, ref_diffusion
 
 
-def build_reference_clean_model(ref_unet, variant, size):
+def build_reference_clean_model(ref_unet, variant, size, n_heads=4):
     v = gs.CLEAN_VARIANTS[variant]
     enc = ref_unet.Encoder(1, gs.TIME_EMBEDDING, cond_on_lsm=v["lsm"], cond_on_topo=v["topo"], cond_on_img=v["cond"],
                            cond_img_dim=(1, size, size) if v["cond"] else None, block_layers=[2, 2, 2, 2],
-                           num_classes=v["num_classes"])
-    dec = ref_unet.Decoder(512, 1, gs.TIME_EMBEDDING, 64)
+                           num_classes=v["num_classes"], n_heads=n_heads)
+    dec = ref_unet.Decoder(512, 1, gs.TIME_EMBEDDING, 64, n_heads=n_heads)
     model = ref_unet.DiffusionNet(enc, dec)
     fill_state_dict_(model, gs.SEED)
     model.eval()
@@ -149,15 +149,38 @@ def gen_clean():
     print("wrote state_dict_clean.json")
 
 
+def gen_heads(package):
+    """G9: forwards with 1, 2 and 8 attention heads (gs.HEAD_CASES) by the reference's own classes; `package` selects
+    which of the two reference packages is imported in this run ("clean" or "danra")."""
+    t = torch.full((2,), 500, dtype=torch.long)
+    out = {}
+    with torch.no_grad():
+        for variant, heads in gs.HEAD_CASES:
+            if (variant in gs.CLEAN_VARIANTS) != (package == "clean"):
+                continue
+            if package == "clean":
+                m = build_reference_clean_model(import_reference_clean()[0], variant, 64, heads)
+            else:
+                m = build_reference_model(import_reference()[0], variant, 64, heads)
+            inp = gs.variant_inputs(variant, 2, 64)
+            out[f"{variant}_heads{heads}_t500"] = m(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"],
+                                                    inp["topo_cond"]).numpy()
+    save(f"heads_{package}", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the T=1000 chain")
     ap.add_argument("--only-state-dict", action="store_true", help="write only state_dict.json")
     ap.add_argument("--only-noise-image", action="store_true", help="write only noise_image.npz")
     ap.add_argument("--only-clean", action="store_true", help="write only clean.npz and state_dict_clean.json")
+    ap.add_argument("--only-heads", choices=("clean", "danra"), help="write only heads_<package>.npz")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(gs.SEED)
+    if args.only_heads:
+        gen_heads(args.only_heads)
+        return
     if args.only_clean:  # the two reference packages define modules of the same names: one package per run
         gen_clean()
         return

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import rel_err
-from model_util import build_clean_model, state_dict_cpu
+from model_util import build_clean_model, build_model, state_dict_cpu
 from oracle import cpu_ref
 from oracle import golden_spec as gs
 
@@ -126,3 +126,42 @@ def test_guided_graph_equals_eager_and_philox_runs(clean, dev):
         du.sample(2, cond_model, 1, y=ci["y"], cond_img=ci["cond_img"], lsm_cond=ci["lsm_cond"], topo_cond=ci["topo_cond"],
                   cfg_scale=1.0)
     cond_model.eval()
+
+
+@pytest.mark.parametrize("variant,heads", gs.HEAD_CASES)
+def test_other_head_counts(golden, dev, variant, heads):
+    """Networks with 1, 2 and 8 heads (head_dim 8 ... 512 over the levels): forward against the reference's golden, a
+    batch-3 forward and the nine attention blocks at batch 2 against the restatement."""
+    from gpu_util import Ops
+    clean_net = variant in gs.CLEAN_VARIANTS
+    g = golden("heads_clean" if clean_net else "heads_danra")
+    model = (build_clean_model if clean_net else build_model)(variant, 64, n_heads=heads)
+    sd = state_dict_cpu(model)
+    model = model.to(dev)
+    assert model.hip_supported()
+    t = torch.full((2,), 500, dtype=torch.long)
+    inp = gs.variant_inputs(variant, 2, 64)
+    on = lambda d: [None if v is None else v.to(dev) for v in (d["y"], d["cond_img"], d["lsm_cond"], d["topo_cond"])]  # noqa: E731
+    with torch.no_grad():
+        out = model(inp["x"].to(dev), t.to(dev), *on(inp))
+        assert rel_err(out.cpu(), g[f"{variant}_heads{heads}_t500"]) < TOL_FWD
+        inp3 = gs.variant_inputs(variant, 3, 64, seed=9)
+        t3 = torch.tensor([999, 40, 1])
+        want = cpu_ref.unet_forward(sd, inp3["x"], t3, inp3["y"], inp3["cond_img"], inp3["lsm_cond"], inp3["topo_cond"],
+                                    clean=clean_net, n_heads=heads)
+        assert rel_err(model(inp3["x"].to(dev), t3.to(dev), *on(inp3)).cpu(), want) < TOL_FWD
+    ops = Ops(model.hip_engine(dev))
+    shapes = [(64, 32), (64, 16), (128, 8), (256, 4), (512, 2), (256, 4), (128, 8), (64, 16), (64, 32)]
+    for idx, (C, side) in enumerate(shapes):
+        x = gs.randn(400 + idx, 2, C, side, side)
+        prefix = f"encoder.attention_layers.{idx}" if idx < 5 else f"decoder.residual_layers.{idx - 5}.attention"
+        if clean_net:
+            want = cpu_ref.image_self_attention_clean(sd, prefix, x, heads)
+        else:
+            want = cpu_ref.image_self_attention(sd, prefix, x, heads)
+        assert rel_err(ops.attention(idx, x.to(dev)).cpu(), want) < TOL_OP, (idx, heads)
+    # a 128x128 image's first level (L = 4096) through the wide-head flash kernel
+    if heads in (1, 2):
+        x = gs.randn(500, 1, 64, 64, 64)
+        fn = cpu_ref.image_self_attention_clean if clean_net else cpu_ref.image_self_attention
+        assert rel_err(ops.attention(0, x.to(dev)).cpu(), fn(sd, "encoder.attention_layers.0", x, heads)) < TOL_OP

@@ -181,3 +181,20 @@ def test_clean_chains(golden, sd_clean, name):
                          data_scaled=c["data_scaled"], noise_fn=fn, trace=trace)
     for i in gs.CLEAN_CHAIN_CHECKPOINTS:
         assert rel_err(trace[i], g[f"chain_{name}_x_after_{i}"]) < 1e-4, i
+
+
+@pytest.mark.parametrize("variant,heads", gs.HEAD_CASES)
+def test_other_head_counts(golden, variant, heads):
+    """1, 2 and 8 attention heads (the clean application's configuration default is 1): restatement and host modules
+    against the reference's forwards."""
+    clean = variant in gs.CLEAN_VARIANTS
+    g = golden("heads_clean" if clean else "heads_danra")
+    model = (build_clean_model if clean else build_model)(variant, 64, n_heads=heads)
+    inp = gs.variant_inputs(variant, 2, 64)
+    t = torch.full((2,), 500, dtype=torch.long)
+    with torch.no_grad():
+        out = cpu_ref.unet_forward(state_dict_cpu(model), inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"],
+                                   inp["topo_cond"], clean=clean, n_heads=heads)
+        assert rel_err(out, g[f"{variant}_heads{heads}_t500"]) < 5e-6
+        out = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert rel_err(out, g[f"{variant}_heads{heads}_t500"]) < 5e-6
