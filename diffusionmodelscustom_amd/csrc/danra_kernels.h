@@ -92,6 +92,7 @@ struct TimeMlpArgs {
     float* dec_emb_out;        // [B][dim] or null
     float* tbias;              // [B][width] or null
     int B, dim, width, enc_width, num_classes;
+    int group;                 // set by the launcher
 };
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream);
 // tbias[b] = table[state->t_fwd][y_b] (table: [T][classes][width]); also publishes state->t_upd = state->t_fwd

@@ -16,13 +16,13 @@ namespace danra {
 // through wave-uniform (scalar) loads.  The sin/cos of a timestep is evaluated once per run of equal
 // timesteps (the sampler gives every image the same one).
 constexpr int TM_ROWS = 16;
-constexpr int TM_GROUP = 65;    // float4 per k-group row
+// float4 per k-group row = images per pass + 1: 65, or 33 when the embedding is wider than 256 (LDS budget)
 constexpr int TM_MAX_CLS = 16;  // label classes served by the per-class table
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
-    extern __shared__ float4 tm_s[];  // [dim/4][TM_GROUP] SiLU(emb) | [TM_ROWS][dim] weights | [TM_MAX_CLS][dim] per-class
+    extern __shared__ float4 tm_s[];  // [dim/4][group] SiLU(emb) | [TM_ROWS][dim] weights | [TM_MAX_CLS][dim] per-class
     __shared__ int s_y[64];
     __shared__ int s_uniform;
     const int tid = threadIdx.x;
@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
     const bool dec_needed = !enc_rows || write_emb;
     const bool enc_needed = enc_rows || write_emb;
     float* s_flat = reinterpret_cast<float*>(tm_s);
+    const int TM_GROUP = a.group;      // row pitch of the staged embeddings
+    const int gsz = TM_GROUP - 1;      // images per pass (<= 64: lanes = images)
     float* s_w = s_flat + (size_t)(a.dim / 4) * TM_GROUP * 4;
     float* s_cls = s_w + (size_t)TM_ROWS * a.dim;
     int t_state = 0;
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
     for (int q = tid; q < TM_ROWS * a.dim / 4; q += 256)
         reinterpret_cast<float4*>(s_w)[q] = reinterpret_cast<const float4*>(a.W + (size_t)row0 * a.dim)[q];
     const bool labels = enc_needed && a.y;
-    for (int b0 = 0; b0 < a.B; b0 += 64) {
-        const int nb = min(64, a.B - b0);
+    for (int b0 = 0; b0 < a.B; b0 += gsz) {
+        const int nb = min(gsz, a.B - b0);
         if (tid == 0) s_uniform = 1;
         __syncthreads();
         if (tid < nb) {
@@ -79,9 +81,10 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
             }
             __syncthreads();
             // lane = image: copy its class row, one float4 group per step
-            const int yb = labels ? s_y[lane] : 0;
+            const int yb = (labels && lane < nb) ? s_y[lane] : 0;
             const float4* src = reinterpret_cast<const float4*>(s_cls) + (size_t)yb * (a.dim / 4);
-            for (int g = tid >> 6; g < a.dim / 4; g += 4) tm_s[g * TM_GROUP + lane] = src[g];
+            if (lane < gsz)
+                for (int g = tid >> 6; g < a.dim / 4; g += 4) tm_s[g * TM_GROUP + lane] = src[g];
         } else {
             for (int j = tid; j < a.dim; j += 256) {
                 const float f_enc = a.enc_inv_freq[j < half ? j : j - half];
@@ -145,9 +148,12 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
     }
 }
 
-hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t stream) {
-    if (a.width % TM_ROWS || a.enc_width % TM_ROWS || a.dim % 8) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)(a.dim / 4) * TM_GROUP * 4 + (size_t)(TM_ROWS + TM_MAX_CLS) * a.dim) * sizeof(float);
+hipError_t launch_time_mlp(const TimeMlpArgs& a_in, hipStream_t stream) {
+    const TimeMlpArgs& a0 = a_in;
+    if (a0.width % TM_ROWS || a0.enc_width % TM_ROWS || a0.dim % 8 || a0.dim > 512) return hipErrorInvalidValue;
+    TimeMlpArgs a = a_in;
+    a.group = a.dim > 256 ? 33 : 65;
+    const size_t lds = ((size_t)(a.dim / 4) * a.group * 4 + (size_t)(TM_ROWS + TM_MAX_CLS) * a.dim) * sizeof(float);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_time_mlp),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -179,7 +179,7 @@ def encoder_forward(sd, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=No
         x = torch.cat([x, topo_cond], dim=1)
     if cond_img is not None:
         x = torch.cat((x, cond_img), dim=1)
-    emb = encoder_pos_encoding(t)
+    emb = encoder_pos_encoding(t, sd[p + "time_projection_layers.0.1.weight"].shape[1])  # = time_embedding
     if y is not None:
         emb = emb + F.embedding(y, sd[p + "label_emb.weight"])
     fmaps = []
@@ -209,7 +209,8 @@ def decoder_block(sd, prefix, fmap, prev_fmap=None, t=None, final=False, faithfu
         assert prev_fmap.shape == out.shape, "feature maps must be of same shape"
         out = out + prev_fmap
     if t is not None:
-        emb = decoder_sinusoidal_embedding(t, faithful=faithful)
+        emb = decoder_sinusoidal_embedding(t, dim=sd[prefix + ".time_projection_layer.1.weight"].shape[1],
+                                           faithful=faithful)
         out = out + time_projection(sd, prefix + ".time_projection_layer", emb)[:, :, None, None]
         out = _attention(sd, prefix + ".attention", out, clean, faithful, n_heads)
     return out if final else F.relu(out)

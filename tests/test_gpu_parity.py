@@ -515,3 +515,25 @@ def test_forward_and_chain_on_the_reference_shipped_inputs(cond64, golden, dev):
     got = du.sample_with_host_noise(x.to(dev), model, noise, y.to(dev), cond_img=cond.to(dev), lsm_cond=lsm.to(dev),
                                     topo_cond=topo.to(dev))
     assert rel_err(got.cpu(), want) < TOL_CHAIN
+
+
+@pytest.mark.parametrize("layers,dim,out_ch", [([1, 2, 1, 3], 128, 1), ([3, 1, 2, 1], 512, 3), ([2, 2, 2, 2], 64, 2)])
+def test_other_geometries(dev, layers, dim, out_ch):
+    """Constructor arguments no reference driver uses but the constructors accept: other BasicBlock counts per layer,
+    other time-embedding sizes, more than one output channel.  Forward against the restatement."""
+    from diffusionmodelscustom_amd import Decoder, DiffusionNet, Encoder
+    from diffusionmodelscustom_amd.synthetic import fill_state_dict_
+    enc = Encoder(1, dim, lsm_tensor=torch.zeros(1, 64, 64), topo_tensor=torch.zeros(1, 64, 64), cond_on_img=True,
+                  cond_img_dim=(1, 64, 64), block_layers=layers, num_classes=4)
+    model = fill_state_dict_(DiffusionNet(enc, Decoder(512, out_ch, dim, 64)), 7).eval()
+    sd = state_dict_cpu(model)
+    model = model.to(dev)
+    assert model.hip_supported()
+    inp = gs.variant_inputs("cond", 2, 64, seed=31)
+    t = torch.tensor([17, 903])
+    with torch.no_grad():
+        want = cpu_ref.unet_forward(sd, inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        got = model(inp["x"].to(dev), t.to(dev), inp["y"].to(dev), inp["cond_img"].to(dev), inp["lsm_cond"].to(dev),
+                    inp["topo_cond"].to(dev))
+    assert got.shape == (2, out_ch, 64, 64)
+    assert rel_err(got.cpu(), want) < TOL_FWD
