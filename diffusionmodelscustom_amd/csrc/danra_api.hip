@@ -718,6 +718,9 @@ int check_ready(danra_handle_s* h, int B, int H, int W) {
     if (!h->packed) return fail(DANRA_ESTATE, "danra_pack_weights has not been called");
     if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
         return fail(DANRA_EINVAL, "B=%d H=%d W=%d: H and W must be positive multiples of 32", B, H, W);
+    // the kernels address every activation tensor with 32-bit byte offsets; the largest one holds 64 floats per pixel
+    if ((unsigned long long)B * H * W >= (1ull << 24))
+        return fail(DANRA_EINVAL, "B=%d H=%d W=%d: B*H*W must stay below 2^24 pixels per call (split the batch)", B, H, W);
     return DANRA_OK;
 }
 

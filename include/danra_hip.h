@@ -83,7 +83,8 @@ int danra_set_freq_tables(danra_handle_t h, const float* enc_inv_freq, const flo
 
 /* Replaces DiffusionNet.forward(x, t, y, cond_img, lsm_cond, topo_cond) (modules:597-616) in eval
  * mode.  x/cond/lsm/topo: [B,1,H,W] planes; t_dev: int64[B]; y_dev: int64[B] or NULL;
- * eps_out_dev: [B,out_channels,H,W].  H and W must be multiples of 32 (five stride-2 stages). */
+ * eps_out_dev: [B,out_channels,H,W].  H and W must be multiples of 32 (five stride-2 stages) and B*H*W below 2^24
+ * pixels per call (e.g. batch 1023 at 128x128), else DANRA_EINVAL. */
 int danra_unet_forward(danra_handle_t h, const float* x_dev, const int64_t* t_dev, const int64_t* y_dev,
                        const float* cond_dev, const float* lsm_dev, const float* topo_dev,
                        float* eps_out_dev, int B, int H, int W, void* stream);

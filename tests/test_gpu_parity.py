@@ -537,3 +537,13 @@ def test_other_geometries(dev, layers, dim, out_ch):
                     inp["topo_cond"].to(dev))
     assert got.shape == (2, out_ch, 64, 64)
     assert rel_err(got.cpu(), want) < TOL_FWD
+
+
+def test_oversized_call_is_refused_before_any_allocation(cond64, dev):
+    """B*H*W >= 2^24 pixels would overflow the kernels' 32-bit offsets: the call is refused with a message."""
+    model, _, _ = cond64
+    x = torch.zeros(1024, 1, 128, 128, device=dev)
+    t = torch.ones(1024, dtype=torch.long, device=dev)
+    y = torch.zeros(1024, dtype=torch.long, device=dev)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="below 2\\^24 pixels"):
+        model(x, t, y, x, x, x)

@@ -131,6 +131,8 @@ def test_create_rejects_bad_geometry_without_gpu():
     names = {lib.danra_param_name(h, i).decode() for i in range(lib.danra_num_params(h))}
     assert "encoder.layer2.0.downsample.0.weight" in names and "encoder.label_emb.weight" in names
     assert lib.danra_set_param(h, b"encoder.nope", None, 0) == -5
+    # shape checks come before any device work: not packed yet -> DANRA_ESTATE, then the geometry messages
+    assert lib.danra_unet_forward(h, None, None, None, None, None, None, None, 1, 64, 64, None) == -2
     assert lib.danra_destroy(h) == 0
 
 
