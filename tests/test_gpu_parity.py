@@ -547,3 +547,33 @@ def test_oversized_call_is_refused_before_any_allocation(cond64, dev):
     y = torch.zeros(1024, dtype=torch.long, device=dev)
     with torch.no_grad(), pytest.raises(RuntimeError, match="below 2\\^24 pixels"):
         model(x, t, y, x, x, x)
+
+
+def test_side_stream_and_two_models_interleaved(cond64, dev):
+    """Everything is enqueued on the caller's current stream: a forward and a sampling run issued on a side stream equal
+    the default-stream results bit for bit; a second model (its own handle and workspace) used in between does not
+    disturb the first one's captured step."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, _ = cond64
+    other = build_model("uncond", 64).to(dev)
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 3, 64, seed=5).items()}
+    t = torch.tensor([5, 500, 995], device=dev)
+    du = DiffusionUtils(8, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    du.noise_seed = 77
+    args = (inp["y"],)
+    kw = dict(cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"])
+    with torch.no_grad():
+        f0 = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        s0 = du.sample(inp["x"], model, *args, **kw)
+        o0 = du.sample(inp["x"], other)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            f1 = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+            s1 = du.sample(inp["x"], model, *args, **kw)
+            o1 = du.sample(inp["x"], other)
+            s2 = du.sample(inp["x"], model, *args, **kw)
+        side.synchronize()
+    assert torch.equal(f0, f1) and torch.equal(s0, s1) and torch.equal(s0, s2) and torch.equal(o0, o1)
+    assert not torch.equal(s0, o0)
