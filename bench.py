@@ -172,10 +172,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    # Rehearsal of the multi-process plumbing on a box with fewer GPUs than ranks (DANRA_BENCH_REHEARSAL=1): ranks
+    # share the visible GPUs and talk over gloo.  Not a measurement; the line it prints says so.
+    rehearsal = os.environ.get("DANRA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w["batch"]
@@ -244,7 +252,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (seeded inputs, deterministic random-init weights, in-kernel Philox noise)",
+            "data": "synthetic (seeded inputs, deterministic random-init weights, in-kernel Philox noise)" +
+                    (" REHEARSAL: ranks share GPUs, gloo backend, not a measurement" if rehearsal else ""),
             "config": {"workload": w["name"], "timesteps": T, "batch_per_gpu": B, "global_batch": world * B,
                        "image": f"{w['size']}x{w['size']}", "parallelism": f"batch-sharded x{world}, weights broadcast "
                        f"once ({sent} bytes), no collective in the loop"},
@@ -253,8 +262,9 @@ def main():
             "whole_path_tflops": value * (T - 1) * fl_img / 1e12 / world,
             "whole_path_frac_of_fp32_peak": value * (T - 1) * fl_img / 1e12 / world / FP32_MATRIX_PEAK_TFLOPS,
             "roofline": {
-                "kernel": "k_flash_hd16 (head_dim-16 flash attention: HIP events around its launches in every 8th denoise "
-                          "step of the timed region)",
+                "kernel": ("k_flash_hd16 (head_dim-16 flash attention" if w.get("heads", 4) == 4 else
+                           "k_flash_wide (flash attention, head_dim 64/32") +
+                          ": HIP events around its launches in every 8th denoise step of the timed region)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP32_MATRIX_PEAK_TFLOPS,

@@ -564,7 +564,8 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     choose_split(a, ws);
     HIP_TRY(launch_igemm(a, st));
     const size_t plane = (size_t)B * L * C;
-    const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && hd == 16 && L % 128 == 0);
+    const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
+    const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
     if (timed) RC_TRY(prof_mark(h, st));
     HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
     if (timed) {

@@ -158,7 +158,7 @@ int danra_set_graph_mode(danra_handle_t h, int enable);
  * launches and their algorithmic FLOPs (2 per multiply-add of QK^T and PV).  danra_unet_forward times every
  * launch; danra_sample times the launches of every 8th denoise step (that step is enqueued kernel by kernel, the
  * others are replayed from the graph as usual), so that the event records do not slow the loop being measured. */
-#define DANRA_PROF_FLASH_ATTENTION 1 /* the head_dim-16 flash attention kernel */
+#define DANRA_PROF_FLASH_ATTENTION 1 /* the flash attention kernels (head_dim 16; head_dim 32/64 with 2 heads or 1 head) */
 int danra_profile_begin(danra_handle_t h, int kind);
 int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, double* total_flops);
 
