@@ -575,6 +575,11 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
     // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
     const bool ff = at.w_ff1 != nullptr;
+    if (ff && C == 64) {  // the three row-local GEMMs of a 64-channel block run as one kernel
+        HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, out, B * L,
+                                   relu ? ACT_RELU : ACT_NONE, st));
+        return DANRA_OK;
+    }
     float* attended = ff ? ws.qkv : out;
     IGemmArgs o = blank_args();
     o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;

@@ -619,6 +619,157 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tail of a 64-channel attention block with a feed-forward part, one kernel for three chained 64x64 GEMMs:
+//   a   = o Wo^T + bo + x                       (output projection + residual)
+//   h   = GELU(LayerNorm(a) W1^T + b1)          (LayerNorm affine already folded into W1, b1)
+//   out = act(a + h W2^T + b2)
+// Every step is local to a token row.  A wave owns 32 rows; with the transposed product of k_gemm_k64 the
+// accumulator layout of one GEMM (lane (row, h) holds columns 8u + 4h .. 8u + 4h + 3, u = 0..7) is exactly the
+// operand-fragment layout of the next one, so the chain runs in registers: no intermediate leaves the wave, the
+// LayerNorm statistics come from the two lanes that share a row, and HBM sees o and x once and out once.
+// The three weight matrices sit in LDS ([64][68] each); the result goes through a wave-private LDS tile so that
+// rows are stored as contiguous 256-byte runs.
+__device__ __forceinline__ void gemm64_frag(const float* __restrict__ Ws, const float4 (&a)[8], float4 (&out)[8], int fr,
+                                            int fh) {
+    constexpr int LDK = 68;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* Bs = Ws + (nt * 32 + fr) * LDK + fh;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[kb].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[kb].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[kb].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * nt + q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O, const float* __restrict__ X,
+                                                     const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W2, const float* __restrict__ b2,
+                                                     float* __restrict__ out, int M, int act) {
+    constexpr int LDK = 68;
+    extern __shared__ __attribute__((aligned(16))) float tail_s[];  // 3 x [64][LDK] weights | 3 x [64] biases | stage tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+    const int fr = lane & 31, fh = (lane >> 5) * 4;
+    float* Ws = tail_s;
+    float* bias_s = tail_s + 3 * 64 * LDK;
+    float* stage = bias_s + 3 * 64 + wave * 32 * LDK;
+    const int m0 = (blockIdx.x * waves + wave) * 32;
+    const int arow = min(m0 + fr, M - 1);
+    // this wave's rows of o and x in fragment order: every load is in flight before the weights are staged
+    float4 a[8], xr[8];
+    {
+        const float* so = O + (size_t)arow * 64 + fh;
+        const float* sx = X + (size_t)arow * 64 + fh;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) a[kb] = *reinterpret_cast<const float4*>(so + kb * 8);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) xr[kb] = *reinterpret_cast<const float4*>(sx + kb * 8);
+    }
+    // the three weight matrices -> LDS, six 16-byte loads per thread in flight at a time
+    {
+        constexpr int NB = 6;
+        constexpr int total = 3 * 64 * 16;
+        for (int q0 = tid; q0 < total; q0 += NB * (int)blockDim.x) {
+            float4 w[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = min(q0 + j * (int)blockDim.x, total - 1);
+                const float* src = q < 1024 ? Wo : (q < 2048 ? W1 : W2);
+                w[j] = *reinterpret_cast<const float4*>(src + (size_t)(q & 1023) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = q0 + j * (int)blockDim.x;
+                if (q < total) *reinterpret_cast<float4*>(Ws + (q >> 4) * LDK + (q & 15) * 4) = w[j];
+            }
+        }
+        if (tid < 64) {
+            bias_s[tid] = bo[tid];
+            bias_s[64 + tid] = b1[tid];
+            bias_s[128 + tid] = b2[tid];
+        }
+    }
+    __syncthreads();
+    if (m0 >= M) return;
+
+    float4 att[8];
+    gemm64_frag(Ws, a, att, fr, fh);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_s + 8 * u + fh);
+        att[u].x += bv.x + xr[u].x; att[u].y += bv.y + xr[u].y; att[u].z += bv.z + xr[u].z; att[u].w += bv.w + xr[u].w;
+    }
+    // LayerNorm over the row's 64 values (two-pass, lanes i and i + 32 hold its two halves)
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (att[u].x + att[u].y) + (att[u].z + att[u].w);
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / 64.0f);
+    float q2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float dx = att[u].x - mean, dy = att[u].y - mean, dz = att[u].z - mean, dw = att[u].w - mean;
+        q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    q2 += __shfl_xor(q2, 32);
+    const float rstd = 1.0f / sqrtf(q2 * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        a[u] = make_float4((att[u].x - mean) * rstd, (att[u].y - mean) * rstd, (att[u].z - mean) * rstd, (att[u].w - mean) * rstd);
+    float4 hid[8];
+    gemm64_frag(Ws + 64 * LDK, a, hid, fr, fh);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_s + 64 + 8 * u + fh);
+        hid[u] = make_float4(gelu(hid[u].x + bv.x), gelu(hid[u].y + bv.y), gelu(hid[u].z + bv.z), gelu(hid[u].w + bv.w));
+    }
+    gemm64_frag(Ws + 2 * 64 * LDK, hid, a, fr, fh);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_s + 128 + 8 * u + fh);
+        float4 v = make_float4(a[u].x + bv.x + att[u].x, a[u].y + bv.y + att[u].y, a[u].z + bv.z + att[u].z,
+                               a[u].w + bv.w + att[u].w);
+        v = activate(act, v);
+        *reinterpret_cast<float4*>(stage + fr * LDK + 8 * u + fh) = v;
+    }
+    // wave-private tile -> memory: 16 consecutive lanes store one whole 256-byte row
+    const int orow = lane >> 4, oc4 = (lane & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = orow + 4 * j;
+        if (m0 + row < M)
+            *reinterpret_cast<float4*>(out + (size_t)(m0 + row) * 64 + oc4) = *reinterpret_cast<const float4*>(stage + row * LDK + oc4);
+    }
+}
+
+hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
+                              const float* b1, const float* W2, const float* b2, float* out, int M, int act,
+                              hipStream_t stream) {
+    const int tasks = (M + 31) / 32;
+    int waves = 8;  // 4 when there are few row tiles (measured: fewer waves only stretch the weight staging)
+    while (waves > 4 && tasks < 128 * waves) waves /= 2;
+    const size_t lds = (size_t)(3 * 64 * 68 + 3 * 64 + waves * 32 * 68) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_tail64),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_attn_tail64, dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x, Wo, bo, W1, b1,
+                       W2, b2, out, M, act);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // The x-plane share of the 8x8 stride-2 stem (one input plane, 64 output channels, K = 64 taps):
 //   out[b][oy][ox][n] = sum_{kh,kw} x[b][2oy-3+kh][2ox-3+kw] * W[n][kh*8+kw] + res[b][oy][ox][n] + tbias[b][n].
 // A workgroup owns an 8x8 patch of output pixels of one image.  Its 22x22 input window (zero padded) and the
