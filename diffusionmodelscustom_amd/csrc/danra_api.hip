@@ -551,7 +551,11 @@ int prof_mark(danra_handle_s* h, hipStream_t st) {
     return DANRA_OK;
 }
 
-int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st) {
+// With ct_w given (64-channel blocks only) the transposed convolution that consumes the block's output is applied
+// in the same kernel as the output projection: ct_out receives [B][2*ct_H][2*ct_W][64] and `out` is not written.
+int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st,
+                  const float* ct_w = nullptr, const float* ct_b = nullptr, float* ct_out = nullptr, int ct_H = 0,
+                  int ct_W = 0) {
     const AttnP& at = h->attn[index];
     const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
     Workspace& ws = h->ws;
@@ -575,9 +579,10 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
     // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
     const bool ff = at.w_ff1 != nullptr;
-    if (ff && C == 64) {  // the three row-local GEMMs of a 64-channel block run as one kernel
-        HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, out, B * L,
-                                   relu ? ACT_RELU : ACT_NONE, st));
+    if (ct_w && C != 64) return fail(DANRA_EINVAL, "fused transposed convolution needs a 64-channel block");
+    if (C == 64 && (ff || ct_w)) {  // the row-local GEMMs behind the attention core of a 64-channel block run as one kernel
+        HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, ct_w, ct_b,
+                                   ct_w ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W, st));
         return DANRA_OK;
     }
     float* attended = ff ? ws.qkv : out;
@@ -656,24 +661,28 @@ int run_time_mlp(danra_handle_s* h, const int64_t* t, SampleState* state, const 
 }
 
 // DecoderBlock k (0..3) given tbias already computed; in [B][Hh][Ww][Cin] -> out [B][2Hh][2Ww][Cout]
+// up_ready: ws.up already holds this block's transposed convolution (the previous block applied it, see run_attention);
+// next_wt/next_bt: apply the NEXT block's transposed convolution to this block's output (into ws.up, `out` unused).
 int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* skip, const float* tbias, float* out,
-                      int B, int Hh, int Ww, hipStream_t st) {
+                      int B, int Hh, int Ww, hipStream_t st, bool up_ready = false, const float* next_wt = nullptr,
+                      const float* next_bt = nullptr) {
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
-    RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
+    if (!up_ready) RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
     HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
     RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
     // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels)
     HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st, ws.pre,
                             skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width));
-    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st));
+    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2));
     return DANRA_OK;
 }
 
-int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st) {
+int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st,
+                    bool up_ready = false) {
     Workspace& ws = h->ws;
-    RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
+    if (!up_ready) RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
     HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
     HIP_TRY(launch_final_conv(ws.up, ws.mean1, ws.rstd1, h->final_conv.w, h->final_conv.bias, eps_nchw, B, 2 * Hh, 2 * Ww,
                               64, h->cfg.out_channels, st));
@@ -708,14 +717,24 @@ int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleStat
         RC_TRY(run_attention(h, L, ws.fpre[L], ws.fmap[L], B, Hc * Wc, 0, st));
         cur = ws.fmap[L];
     }
+    // A 64-channel block's output feeds only the next block's transposed convolution, which is row-local like the
+    // block's own output projection: the two run as one kernel and the block's output never reaches memory.
     const float* din = ws.fmap[4];
+    bool up_ready = false;
     for (int k = 0; k < 4; ++k) {
         float* dout = (k & 1) ? ws.outB : ws.outA;
-        RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st));
+        const float *next_wt = nullptr, *next_bt = nullptr;
+        // (measured: pays from 32768 token rows on; below that the per-workgroup weight staging outweighs the saved pass)
+        if (h->dec[k].Cout == 64 && (long)B * 4 * Hc * Wc >= 32768) {
+            next_wt = (k < 3) ? h->dec[k + 1].wt : h->final_wt;
+            next_bt = (k < 3) ? h->dec[k + 1].bt : h->final_bt;
+        }
+        RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st, up_ready, next_wt, next_bt));
+        up_ready = next_wt != nullptr;
         din = dout;
         Hc *= 2; Wc *= 2;
     }
-    RC_TRY(run_final_block(h, din, eps, B, Hc, Wc, st));
+    RC_TRY(run_final_block(h, din, eps, B, Hc, Wc, st, up_ready));
     return DANRA_OK;
 }
 

@@ -48,11 +48,14 @@ struct IGemmArgs {
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
 
-// Tail of a 64-channel attention block with a feed-forward part (M token rows of 64 floats):
-//   a = o Wo^T + bo + x;  out = act(a + GELU(LayerNorm(a) W1^T + b1) W2^T + b2), LayerNorm affine folded into W1/b1.
+// Tail of a 64-channel attention block as one kernel (M token rows of 64 floats, every step local to a row):
+//   a = o Wo^T + bo + x;  with W1: a += GELU(LayerNorm(a) W1^T + b1) W2^T + b2 (LayerNorm affine folded into W1/b1);
+//   v = act(a);  with Wt ([256][64], rows (dy, dx, co)): the kernel-2 stride-2 transposed convolution that consumes v is
+//   applied as well and `out` is its [B][2*ct_H][2*ct_W][64] result (v itself is not stored); else out = v.
+// At least one of W1 and Wt must be given.
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
-                              const float* b1, const float* W2, const float* b2, float* out, int M, int act,
-                              hipStream_t stream);
+                              const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
+                              float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream);
 
 // One input plane's share of the 8x8 stride-2 pad-3 stem: out = conv(x; Wt[64][8x8], row stride ldw) [+ res] [+ tbias[b]],
 // x: [B][H][W], out/res: [B][H/2][W/2][64]; H and W multiples of 16.

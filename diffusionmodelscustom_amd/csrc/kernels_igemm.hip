@@ -651,18 +651,27 @@ __device__ __forceinline__ void gemm64_frag(const float* __restrict__ Ws, const 
     }
 }
 
+// FF: the feed-forward part is present (else the chain is the output projection alone).
+// CT: the result is not stored but fed, still in registers, to the transposed convolution that consumes it
+//     (kernel 2, stride 2, 64 -> 64 channels = a 64 -> 256 GEMM whose column block q = (dy, dx) lands on output
+//     pixel (2y + dy, 2x + dx)): up[b][2y+dy][2x+dx][co] = sum_ci v[b][y][x][ci] * Wt[q*64 + co][ci] + bt[q*64 + co].
+template <bool FF, bool CT>
 __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O, const float* __restrict__ X,
                                                      const float* __restrict__ Wo, const float* __restrict__ bo,
                                                      const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W2, const float* __restrict__ b2,
-                                                     float* __restrict__ out, int M, int act) {
+                                                     const float* __restrict__ Wt, const float* __restrict__ bt,
+                                                     float* __restrict__ out, int M, int act, int ct_H, int ct_W) {
     constexpr int LDK = 68;
-    extern __shared__ __attribute__((aligned(16))) float tail_s[];  // 3 x [64][LDK] weights | 3 x [64] biases | stage tiles
+    constexpr int NW = FF ? 3 : 1;             // 64x64 matrices of the chain
+    constexpr int WROWS = NW * 64 + (CT ? 256 : 0);
+    constexpr int LDO = CT ? 36 : LDK;         // row pitch of the wave's output tile (32 or 64 columns wide)
+    extern __shared__ __attribute__((aligned(16))) float tail_s[];  // [WROWS][LDK] weights | [WROWS] biases | output tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
     const int fr = lane & 31, fh = (lane >> 5) * 4;
     float* Ws = tail_s;
-    float* bias_s = tail_s + 3 * 64 * LDK;
-    float* stage = bias_s + 3 * 64 + wave * 32 * LDK;
+    float* bias_s = tail_s + WROWS * LDK;
+    float* stage = bias_s + WROWS + wave * 32 * LDO;
     const int m0 = (blockIdx.x * waves + wave) * 32;
     const int arow = min(m0 + fr, M - 1);
     // this wave's rows of o and x in fragment order: every load is in flight before the weights are staged
@@ -675,17 +684,22 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) xr[kb] = *reinterpret_cast<const float4*>(sx + kb * 8);
     }
-    // the three weight matrices -> LDS, six 16-byte loads per thread in flight at a time
+    // the weight matrices -> LDS, six 16-byte loads per thread in flight at a time
     {
         constexpr int NB = 6;
-        constexpr int total = 3 * 64 * 16;
+        constexpr int total = WROWS * 16;
         for (int q0 = tid; q0 < total; q0 += NB * (int)blockDim.x) {
             float4 w[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int q = min(q0 + j * (int)blockDim.x, total - 1);
-                const float* src = q < 1024 ? Wo : (q < 2048 ? W1 : W2);
-                w[j] = *reinterpret_cast<const float4*>(src + (size_t)(q & 1023) * 4);
+                const float* src;
+                int r = q;
+                if (q < 1024) src = Wo;
+                else if (FF && q < 2048) { src = W1; r = q - 1024; }
+                else if (FF && q < 3072) { src = W2; r = q - 2048; }
+                else { src = Wt; r = q - NW * 1024; }
+                w[j] = *reinterpret_cast<const float4*>(src + (size_t)r * 4);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -695,9 +709,12 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
         }
         if (tid < 64) {
             bias_s[tid] = bo[tid];
-            bias_s[64 + tid] = b1[tid];
-            bias_s[128 + tid] = b2[tid];
+            if (FF) {
+                bias_s[64 + tid] = b1[tid];
+                bias_s[128 + tid] = b2[tid];
+            }
         }
+        if (CT && tid < 256) bias_s[NW * 64 + tid] = bt[tid];
     }
     __syncthreads();
     if (m0 >= M) return;
@@ -709,64 +726,124 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + 8 * u + fh);
         att[u].x += bv.x + xr[u].x; att[u].y += bv.y + xr[u].y; att[u].z += bv.z + xr[u].z; att[u].w += bv.w + xr[u].w;
     }
-    // LayerNorm over the row's 64 values (two-pass, lanes i and i + 32 hold its two halves)
-    float s = 0.f;
+    if (FF) {
+        // LayerNorm over the row's 64 values (two-pass, lanes i and i + 32 hold its two halves)
+        float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += (att[u].x + att[u].y) + (att[u].z + att[u].w);
-    s += __shfl_xor(s, 32);
-    const float mean = s * (1.0f / 64.0f);
-    float q2 = 0.f;
+        for (int u = 0; u < 8; ++u) s += (att[u].x + att[u].y) + (att[u].z + att[u].w);
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 64.0f);
+        float q2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const float dx = att[u].x - mean, dy = att[u].y - mean, dz = att[u].z - mean, dw = att[u].w - mean;
-        q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        for (int u = 0; u < 8; ++u) {
+            const float dx = att[u].x - mean, dy = att[u].y - mean, dz = att[u].z - mean, dw = att[u].w - mean;
+            q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q2 += __shfl_xor(q2, 32);
+        const float rstd = 1.0f / sqrtf(q2 * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            a[u] = make_float4((att[u].x - mean) * rstd, (att[u].y - mean) * rstd, (att[u].z - mean) * rstd,
+                               (att[u].w - mean) * rstd);
+        float4 hid[8];
+        gemm64_frag(Ws + 64 * LDK, a, hid, fr, fh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias_s + 64 + 8 * u + fh);
+            hid[u] = make_float4(gelu(hid[u].x + bv.x), gelu(hid[u].y + bv.y), gelu(hid[u].z + bv.z), gelu(hid[u].w + bv.w));
+        }
+        gemm64_frag(Ws + 2 * 64 * LDK, hid, a, fr, fh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias_s + 128 + 8 * u + fh);
+            att[u] = make_float4(a[u].x + bv.x + att[u].x, a[u].y + bv.y + att[u].y, a[u].z + bv.z + att[u].z,
+                                 a[u].w + bv.w + att[u].w);
+        }
     }
-    q2 += __shfl_xor(q2, 32);
-    const float rstd = 1.0f / sqrtf(q2 * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        a[u] = make_float4((att[u].x - mean) * rstd, (att[u].y - mean) * rstd, (att[u].z - mean) * rstd, (att[u].w - mean) * rstd);
-    float4 hid[8];
-    gemm64_frag(Ws + 64 * LDK, a, hid, fr, fh);
+    for (int u = 0; u < 8; ++u) att[u] = activate(act, att[u]);
+
+    if (!CT) {
+        // wave-private tile -> memory: 16 consecutive lanes store one whole 256-byte row
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_s + 64 + 8 * u + fh);
-        hid[u] = make_float4(gelu(hid[u].x + bv.x), gelu(hid[u].y + bv.y), gelu(hid[u].z + bv.z), gelu(hid[u].w + bv.w));
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(stage + fr * LDO + 8 * u + fh) = att[u];
+        const int orow = lane >> 4, oc4 = (lane & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = orow + 4 * j;
+            if (m0 + row < M)
+                *reinterpret_cast<float4*>(out + (size_t)(m0 + row) * 64 + oc4) =
+                    *reinterpret_cast<const float4*>(stage + row * LDO + oc4);
+        }
+        return;
     }
-    gemm64_frag(Ws + 2 * 64 * LDK, hid, a, fr, fh);
+    // ---- transposed convolution: 8 column blocks of 32; block nt = (tap q = nt / 2, channels 32*(nt & 1) ..)
+    const int orow = lane >> 3, oc4 = (lane & 7) * 4;  // 8 consecutive lanes store 128 contiguous bytes of one row
+    unsigned long long rbase[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_s + 128 + 8 * u + fh);
-        float4 v = make_float4(a[u].x + bv.x + att[u].x, a[u].y + bv.y + att[u].y, a[u].z + bv.z + att[u].z,
-                               a[u].w + bv.w + att[u].w);
-        v = activate(act, v);
-        *reinterpret_cast<float4*>(stage + fr * LDK + 8 * u + fh) = v;
+    for (int j = 0; j < 4; ++j) {
+        const int m = min(m0 + orow + 8 * j, M - 1);
+        const int hw = ct_H * ct_W;
+        const int bimg = m / hw, r = m - bimg * hw, y = r / ct_W, x = r - y * ct_W;
+        rbase[j] = (((unsigned long long)bimg * 2 * ct_H + 2 * y) * 2 * ct_W + 2 * x) * 64;
     }
-    // wave-private tile -> memory: 16 consecutive lanes store one whole 256-byte row
-    const int orow = lane >> 4, oc4 = (lane & 15) * 4;
+    const float* Wts = Ws + NW * 64 * LDK;
+    const float* bts = bias_s + NW * 64;
+    for (int nt = 0; nt < 8; ++nt) {
+        f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = orow + 4 * j;
-        if (m0 + row < M)
-            *reinterpret_cast<float4*>(out + (size_t)(m0 + row) * 64 + oc4) = *reinterpret_cast<const float4*>(stage + row * LDK + oc4);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* Bs = Wts + (nt * 32 + fr) * LDK + fh;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const float4 bw = *reinterpret_cast<const float4*>(Bs + kb * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.x, att[kb].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.y, att[kb].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.z, att[kb].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.w, att[kb].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(stage + fr * LDO + 8 * g + fh) =
+                make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        const float4 bv = *reinterpret_cast<const float4*>(bts + nt * 32 + oc4);
+        const int q = nt >> 1;
+        const unsigned long long co = ((unsigned long long)(q >> 1) * 2 * ct_W + (q & 1)) * 64 + (nt & 1) * 32 + oc4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (m0 + orow + 8 * j < M) *reinterpret_cast<float4*>(out + rbase[j] + co) = v;
+        }
     }
 }
 
-hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
-                              const float* b1, const float* W2, const float* b2, float* out, int M, int act,
-                              hipStream_t stream) {
+template <bool FF, bool CT>
+static hipError_t launch_attn_tail64_t(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
+                                       const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
+                                       float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream) {
     const int tasks = (M + 31) / 32;
-    int waves = 8;  // 4 when there are few row tiles (measured: fewer waves only stretch the weight staging)
+    int waves = (FF && CT) ? 4 : 8;  // LDS budget; 4 also when there are few row tiles (fewer only stretch the staging)
     while (waves > 4 && tasks < 128 * waves) waves /= 2;
-    const size_t lds = (size_t)(3 * 64 * 68 + 3 * 64 + waves * 32 * 68) * sizeof(float);
+    const int wrows = (FF ? 3 : 1) * 64 + (CT ? 256 : 0);
+    const size_t lds = (size_t)(wrows * 68 + wrows + waves * 32 * (CT ? 36 : 68)) * sizeof(float);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_tail64),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_tail64<FF, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_attn_tail64, dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x, Wo, bo, W1, b1,
-                       W2, b2, out, M, act);
+    hipLaunchKernelGGL((k_attn_tail64<FF, CT>), dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x, Wo,
+                       bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W);
     return hipGetLastError();
+}
+
+hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
+                              const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
+                              float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream) {
+    if (W1 && Wt) return launch_attn_tail64_t<true, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
+    if (W1) return launch_attn_tail64_t<true, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
+    if (Wt) return launch_attn_tail64_t<false, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
+    return hipErrorInvalidValue;  // the plain output projection goes through launch_igemm
 }
 
 // ------------------------------------------------------------------------------------------------
