@@ -298,6 +298,15 @@ class DiffusionNet(nn.Module):
                 topo_cond: Optional[torch.Tensor] = None):
         if self._hip_eligible(x):
             return self.hip_engine(x.device).forward(x, t, *self.hip_call_arguments(y, cond_img, lsm_cond, topo_cond))
+        if (not self.training and not torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
+                and not getattr(self, '_warned_not_native', False)):
+            # an inference call on the GPU that the native library cannot take is never silent
+            import warnings
+            self._warned_not_native = True
+            why = ('the network geometry is outside what libdanra_hip.so implements' if not self.hip_supported() else
+                   f'x has dtype {x.dtype} and shape {tuple(x.shape)} (needs float32 [B, 1, H, W] with H, W multiples of 32)')
+            warnings.warn(f'DiffusionNet.forward runs as a torch-op composition, not in the HIP library: {why}',
+                          RuntimeWarning, stacklevel=2)
         enc_fmaps = self.encoder(x, t=t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)
         return self.decoder(*enc_fmaps, t=t)
 

@@ -577,3 +577,16 @@ def test_side_stream_and_two_models_interleaved(cond64, dev):
         side.synchronize()
     assert torch.equal(f0, f1) and torch.equal(s0, s1) and torch.equal(s0, s2) and torch.equal(o0, o1)
     assert not torch.equal(s0, o0)
+
+
+def test_unsupported_geometry_on_the_gpu_is_announced(dev):
+    """A network the native library does not implement (3 heads) still works on the GPU through the torch composition,
+    but says so: the HIP path never degrades silently."""
+    from diffusionmodelscustom_amd import Decoder, DiffusionNet, Encoder
+    from diffusionmodelscustom_amd.synthetic import fill_state_dict_
+    model = fill_state_dict_(DiffusionNet(Encoder(1, 256, n_heads=16), Decoder(512, 1, 256, 64, n_heads=16)), 1).eval().to(dev)
+    assert not model.hip_supported()
+    x = gs.randn(3, 1, 1, 32, 32).to(dev)
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="not in the HIP library"):
+        out = model(x, torch.tensor([5], device=dev))
+    assert out.shape == x.shape and torch.isfinite(out).all()
