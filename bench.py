@@ -28,12 +28,12 @@ from diffusionmodelscustom_amd.synthetic import fill_state_dict_, synthetic_inpu
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix/vector peak
 
 WORKLOADS = {
-    # BASELINE.json configs[1..3]
+    # the benchmark configurations: unconditional 64x64, conditional 64x64 (the headline), conditional 128x128
     "c2": dict(name="DANRA unconditional 64x64, T=1000, batch 32/GPU", size=64, batch=32, cond=False),
     "c3": dict(name="DANRA conditional (lsm+topo+cond image+season embedding) 64x64, T=1000, batch 64/GPU", size=64,
                batch=64, cond=True),
     "c4": dict(name="DANRA conditional 128x128, T=1000, batch 32/GPU", size=128, batch=32, cond=True),
-    # the DDPM_clean_application variant (attention blocks with a feed-forward part); not BASELINE configs
+    # the DDPM_clean_application variant (attention blocks with a feed-forward part); secondary workloads
     "clean": dict(name="clean-application network, conditional (lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU",
                   size=64, batch=64, cond=True, clean=True),
     "clean_h1": dict(name="clean-application network with its configuration default of 1 attention head, conditional "
@@ -81,7 +81,7 @@ def unet_flops_per_image(size, in_ch, attn_ff=False):
 def flash_traffic_per_launch(workload, batch):
     """HBM bytes per k_flash_hd16 launch from the committed PMC measurement (rocprofv3 --pmc FETCH_SIZE with the
     gfx950 x2 correction + WRITE_SIZE, separate passes: tools/pmc_traffic.sh), averaged like `achieved` over the
-    launches of one UNet evaluation (two at L=1024, two at L=256).  Only measured for C3 at batch 64."""
+    launches of one UNet evaluation (two at L=1024, two at L=256).  Only measured for the conditional 64x64 workload (c3) at batch 64."""
     path = os.path.join(ROOT, "profiles", "r01_flash_traffic.json")
     if workload != "c3" or batch != 64 or not os.path.exists(path):
         return None

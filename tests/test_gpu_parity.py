@@ -271,7 +271,7 @@ def test_sampling_chain_T1000(cond64, golden, dev):
 
 
 def test_full_size_batch_properties(cond64, dev):
-    """BASELINE-size batch (B = 64, 64x64 conditional): each image's result is independent of its batch
+    """Benchmark-size batch (B = 64, 64x64 conditional): each image's result is independent of its batch
     neighbours (eval-mode network has no cross-sample statistic), checked against B = 1 runs, and
     Philox sampling is deterministic in its seed."""
     from diffusionmodelscustom_amd import DiffusionUtils
@@ -368,7 +368,7 @@ def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
 
 @pytest.mark.parametrize("sched", ["linear", "cosine"])
 def test_noise_image_bit_exact_and_philox(golden, dev, sched):
-    """Forward process kernel (next-row f1, danra_noise_image): bit-exact against the reference's noiseImage given
+    """Forward process kernel (danra_noise_image, used by the training step): bit-exact against the reference's noiseImage given
     its draw; the in-kernel draw is returned, standard normal, reproducible in the seed and consistent with the
     noisy image it produced."""
     from diffusionmodelscustom_amd import DiffusionUtils, hip_engine
@@ -428,7 +428,7 @@ def test_sampler_state_is_rebuilt_between_calls(cond64, dev):
 
 
 def test_c1_unconditional_32x32_T200_chain(dev):
-    """BASELINE config C1 (the reference's own CPU-runnable case restated: unconditional 1x32x32, T=200, B=4,
+    """The smallest benchmark configuration (the reference's own CPU-runnable case restated: unconditional 1x32x32, T=200, B=4,
     linear betas): the whole sampling call on the GPU against the CPU restatement with the same host noise, and
     the cosine schedule on the same model."""
     from diffusionmodelscustom_amd import DiffusionUtils

@@ -160,7 +160,7 @@ def test_noise_image_cpu_path_matches_golden(golden):
 
 
 def test_checkpoint_round_trip_and_training_step(tmp_path):
-    """The reference's checkpoint format and training step on top of these modules (next rows f1/f3):
+    """The reference's checkpoint format and training step on top of these modules:
     torch.save({'network_params', 'optimizer_params'}) as training_DANRA_conditional.py:755-772 writes it, strict
     load into a fresh model, one AdamW step on the noise-prediction loss (training:963-984) that changes the weights."""
     from diffusionmodelscustom_amd import DiffusionUtils
@@ -252,7 +252,7 @@ def test_clean_diffusion_utils_surface_and_guided_chain(golden):
 
 
 def test_generation_files_have_the_reference_layout(tmp_path):
-    """The six .npz files of a generation run (next row f3) carry the same key, dtype and per-sample shape as the files
+    """The six .npz files of a generation run carry the same key, dtype and per-sample shape as the files
     the reference ships (final_generated_samples/, metadata in tests/golden/generation_files.json), and load back."""
     from diffusionmodelscustom_amd import generation_io as gio
     with open(os.path.join(GOLDEN_DIR, "generation_files.json")) as f:

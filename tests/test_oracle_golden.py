@@ -121,7 +121,7 @@ def test_update_matches_reference_statements():
 
 @pytest.mark.parametrize("sched", ["linear", "cosine"])
 def test_noise_image_bit_exact(golden, sched):
-    """Forward process (next-row f1): the restatement reproduces the reference's noiseImage given its own draw."""
+    """Forward process (used by the training step): the restatement reproduces the reference's noiseImage given its own draw."""
     g = golden("noise_image")
     sc = golden("schedule")
     alpha_hat = torch.from_numpy(sc[f"{sched}_{gs.NOISE_IMAGE_T}_alpha_hat"])

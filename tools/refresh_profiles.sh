@@ -16,7 +16,7 @@ rm -f "$OUT"/prof/r_kernel_trace.csv
 timeout -k 10 300 rocprofv3 --kernel-trace -d "$OUT/prof_t" -o r1 --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --timesteps 200 --no-cpu-baseline --no-kernel-timing > "$OUT/prof_t.log" 2>&1
 cd "$ROOT" && python3 tools/prof_forward.py "$OUT/prof_t/r1_kernel_trace.csv" > "$OUT/forward_timeline_T200.txt"
 rm -f "$OUT"/prof_t/r1_kernel_trace.csv
-# the other BASELINE configurations (bench lines only)
+# the other two benchmark configurations (bench lines only)
 cd "$ROOT"
 timeout -k 10 400 python3 bench.py --workload c2 > "$OUT/bench_c2.log" 2>&1
 grep -o '{"metric.*' "$OUT/bench_c2.log" > "$OUT/bench_c2.json"
