@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
         if (tid == 0) s_uniform = 1;
         __syncthreads();
         if (tid < nb) {
-            const int yb = labels ? (int)a.y[b0 + tid] : 0;
+            const int yb = labels ? (int)min(max(a.y[b0 + tid], (int64_t)0), (int64_t)(a.num_classes - 1)) : 0;  // clamped
             s_y[tid] = yb;
             const bool same_t = a.state || a.t[b0 + tid] == a.t[b0];
             if (!same_t || (labels && (yb < 0 || yb >= TM_MAX_CLS))) s_uniform = 0;
@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeMlpArgs a) {
                         t_prev = ti;
                     }
                     float e = e_base;
-                    if (labels) e += a.label_emb[(size_t)a.y[b] * a.dim + j];
+                    if (labels) {  // labels are clamped to the table: an invalid one must not become a wild read
+                        const long long yc = min(max(a.y[b], (int64_t)0), (int64_t)(a.num_classes - 1));
+                        e += a.label_emb[(size_t)yc * a.dim + j];
+                    }
                     if (write_emb) {
                         if (a.enc_emb_out) a.enc_emb_out[(size_t)b * a.dim + j] = e;
                         if (a.dec_emb_out) a.dec_emb_out[(size_t)b * a.dim + j] = d_base;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void k_tbias_gather(SampleState* state, const 
     const int w4 = width / 4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * w4; i += gridDim.x * blockDim.x) {
         const int b = i / w4, j = i - b * w4;
-        const int c = y ? (int)y[b] : 0;
+        const int c = y ? (int)min(max(y[b], (int64_t)0), (int64_t)(classes - 1)) : 0;  // clamped: never a wild read
         reinterpret_cast<float4*>(tbias)[i] =
             reinterpret_cast<const float4*>(table + ((size_t)t * classes + c) * width)[j];
     }

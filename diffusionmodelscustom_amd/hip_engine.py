@@ -126,6 +126,15 @@ def _i64(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _check_labels(y, num_classes):
+    """The reference's nn.Embedding refuses an out-of-range label; the kernels clamp it (memory safety), so the
+    refusal happens here (one device read per call)."""
+    if y is not None and num_classes > 0 and y.numel():
+        lo, hi = int(y.min()), int(y.max())
+        if lo < 0 or hi >= num_classes:
+            raise IndexError(f"label {lo if lo < 0 else hi} is out of range for the {num_classes}-class label embedding")
+
+
 def reference_freq_tables(dim):
     """The two frequency tables evaluated with the torch CPU expressions of the reference
     (modules_DANRA_conditional.py:204-207 and :57), so that they round exactly as it does."""
@@ -231,6 +240,7 @@ class UNetEngine:
     def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):
         x = _f32(x, "x")
         B, _, H, W = x.shape
+        _check_labels(y, self.cfg.num_classes)
         out = torch.empty((B, self.out_channels, H, W), device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             _check(self.lib, self.lib.danra_unet_forward(
@@ -261,6 +271,7 @@ class UNetEngine:
         cfg_scale > 0: classifier-free guidance (two evaluations per step); noise_scale multiplies every draw."""
         x = _f32(x, "x")
         B, _, H, W = x.shape
+        _check_labels(y, self.cfg.num_classes)
         T = int(betas.numel())
         hb = betas.detach().to("cpu", torch.float32).contiguous()
         ha = alphas.detach().to("cpu", torch.float32).contiguous()

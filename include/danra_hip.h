@@ -82,7 +82,8 @@ int danra_pack_weights(danra_handle_t h, void* stream);
 int danra_set_freq_tables(danra_handle_t h, const float* enc_inv_freq, const float* dec_div, int n);
 
 /* Replaces DiffusionNet.forward(x, t, y, cond_img, lsm_cond, topo_cond) (modules:597-616) in eval
- * mode.  x/cond/lsm/topo: [B,1,H,W] planes; t_dev: int64[B]; y_dev: int64[B] or NULL;
+ * mode.  x/cond/lsm/topo: [B,1,H,W] planes; t_dev: int64[B]; y_dev: int64[B] or NULL (labels outside
+ * [0, num_classes) are clamped into it: the caller validates them, as the shipped binding does);
  * eps_out_dev: [B,out_channels,H,W].  H and W must be multiples of 32 (five stride-2 stages) and B*H*W below 2^24
  * pixels per call (e.g. batch 1023 at 128x128), else DANRA_EINVAL. */
 int danra_unet_forward(danra_handle_t h, const float* x_dev, const int64_t* t_dev, const int64_t* y_dev,

@@ -590,3 +590,20 @@ def test_unsupported_geometry_on_the_gpu_is_announced(dev):
     with torch.no_grad(), pytest.warns(RuntimeWarning, match="not in the HIP library"):
         out = model(x, torch.tensor([5], device=dev))
     assert out.shape == x.shape and torch.isfinite(out).all()
+
+
+def test_out_of_range_label_is_refused(cond64, dev):
+    """nn.Embedding in the reference raises on a label outside the table; so does the binding (the kernels themselves
+    clamp, so that a bad label can never become an out-of-bounds read)."""
+    model, _, ops = cond64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 2, 64).items()}
+    bad = torch.tensor([1, 4], device=dev)
+    with torch.no_grad(), pytest.raises(IndexError, match="out of range"):
+        model(inp["x"], torch.tensor([3, 3], device=dev), bad, inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+    # through the raw C entry point the label is clamped to the last class
+    t = torch.tensor([9, 9], device=dev)
+    _, _, a = ops.time_embed(t, torch.tensor([3, 3], device=dev))
+    for wild in (77, 5, -2):
+        want = a if wild > 0 else ops.time_embed(t, torch.tensor([3, 0], device=dev))[2]
+        _, _, b = ops.time_embed(t, torch.tensor([3, wild], device=dev))
+        assert torch.equal(want, b), wild
