@@ -1104,9 +1104,19 @@ static int op_workspace(danra_handle_t h, int B, long tokens64) {
     return ensure_workspace(h, B, side, side);
 }
 
+// argument checks shared by the per-op entry points: a bad call is refused, never launched
+static int op_args(const void* in, const void* out, int B, long extent) {
+    if (!in || !out) return fail(DANRA_EINVAL, "null tensor pointer");
+    if (B <= 0 || extent <= 0) return fail(DANRA_EINVAL, "B=%d and the spatial extent %ld must be positive", B, extent);
+    if ((unsigned long long)B * (unsigned long long)extent >= (1ull << 24))
+        return fail(DANRA_EINVAL, "B=%d x %ld pixels: must stay below 2^24 per call", B, extent);
+    return DANRA_OK;
+}
+
 int danra_attention(danra_handle_t h, int index, const float* x, float* out, int B, int HW, int relu, void* stream) {
     if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
     if (index < 0 || index > 8) return fail(DANRA_EINVAL, "attention index out of range");
+    RC_TRY(op_args(x, out, B, HW));
     const int C = h->attn[index].C;
     RC_TRY(op_workspace(h, B, ((long)HW * C + 63) / 64));
     return run_attention(h, index, x, out, B, HW, relu, (hipStream_t)stream);
@@ -1123,12 +1133,15 @@ int danra_conv1(danra_handle_t h, const float* x, const float* lsm, const float*
     if (h->cfg.has_cond) planes[np++] = cond;
     for (int i = 0; i < np; ++i)
         if (!planes[i]) return fail(DANRA_EINVAL, "missing input plane %d", i);
+    RC_TRY(op_args(x, out, B, (long)H * W));
+    if (H % 16 || W % 16) return fail(DANRA_EINVAL, "H=%d W=%d must be multiples of 16", H, W);
     RC_TRY(op_workspace(h, B, (long)(H / 2) * (W / 2)));
     return run_stem(h, planes, out, B, H, W, nullptr, false, (hipStream_t)stream);
 }
 
 int danra_conv2_bn_relu(danra_handle_t h, const float* x, float* out, int B, int H, int W, void* stream) {
     if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
+    RC_TRY(op_args(x, out, B, (long)H * W));
     RC_TRY(op_workspace(h, B, 1));
     return run_conv(h, h->conv2, x, out, B, H, W, nullptr, 1, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -1136,6 +1149,7 @@ int danra_conv2_bn_relu(danra_handle_t h, const float* x, float* out, int B, int
 int danra_resnet_layer(danra_handle_t h, int level, const float* x, float* out, int B, int H, int W, void* stream) {
     if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
     if (level < 1 || level > 4) return fail(DANRA_EINVAL, "level must be 1..4");
+    RC_TRY(op_args(x, out, B, (long)H * W));
     const int cin = level == 1 ? 64 : (64 << (level - 2));
     RC_TRY(op_workspace(h, B, 4 * (((long)H * W * cin + 63) / 64)));
     return run_layer(h, level, x, out, B, H, W, nullptr, (hipStream_t)stream);
@@ -1145,6 +1159,8 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap, const fl
                         int B, int H, int W, void* stream) {
     if (!h || !h->packed) return fail(DANRA_ESTATE, "weights not packed");
     if (block < 0 || block > 4) return fail(DANRA_EINVAL, "block must be 0..4");
+    RC_TRY(op_args(fmap, out, B, 4L * H * W));
+    if (block < 4 && !skip) return fail(DANRA_EINVAL, "skip_nhwc is required by blocks 0..3");
     hipStream_t st = (hipStream_t)stream;
     if (block == 4) {
         RC_TRY(op_workspace(h, B, (long)H * W));
@@ -1159,7 +1175,8 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap, const fl
 }
 
 int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* stream) {
-    if (C % 32) return fail(DANRA_EINVAL, "C must be a multiple of 32");
+    if (C <= 0 || C % 32) return fail(DANRA_EINVAL, "C must be a positive multiple of 32");
+    RC_TRY(op_args(x, out, B, HW));
     float* stats = nullptr;
     HIP_TRY(hipMalloc((void**)&stats, (size_t)2 * B * C * 4));
     hipStream_t st = (hipStream_t)stream;
@@ -1172,10 +1189,14 @@ int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* 
 }
 
 int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream) {
+    RC_TRY(op_args(src, dst, B, HW));
+    if (C <= 0) return fail(DANRA_EINVAL, "C must be positive");
     HIP_TRY(launch_nchw_to_nhwc(src, dst, B, C, HW, (hipStream_t)stream));
     return DANRA_OK;
 }
 int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void* stream) {
+    RC_TRY(op_args(src, dst, B, HW));
+    if (C <= 0) return fail(DANRA_EINVAL, "C must be positive");
     HIP_TRY(launch_nhwc_to_nchw(src, dst, B, C, HW, (hipStream_t)stream));
     return DANRA_OK;
 }

@@ -607,3 +607,21 @@ def test_out_of_range_label_is_refused(cond64, dev):
         want = a if wild > 0 else ops.time_embed(t, torch.tensor([3, 0], device=dev))[2]
         _, _, b = ops.time_embed(t, torch.tensor([3, wild], device=dev))
         assert torch.equal(want, b), wild
+
+
+def test_per_op_entry_points_refuse_bad_arguments(cond64, dev):
+    """Null pointers, non-positive sizes and out-of-range selectors come back as DANRA_EINVAL with a message."""
+    import ctypes
+    model, _, ops = cond64
+    lib, h = ops.lib, ops.h
+    x = torch.zeros(1, 32, 32, 64, device=dev)
+    p = ctypes.c_void_p(x.data_ptr())
+    assert lib.danra_attention(h, 9, p, p, 1, 1024, 0, None) == -1
+    assert lib.danra_attention(h, 0, None, p, 1, 1024, 0, None) == -1 and b"null" in lib.danra_last_error()
+    assert lib.danra_attention(h, 0, p, p, 0, 1024, 0, None) == -1
+    assert lib.danra_resnet_layer(h, 5, p, p, 1, 16, 16, None) == -1
+    assert lib.danra_resnet_layer(h, 1, p, p, 1, -16, 16, None) == -1
+    assert lib.danra_decoder_block(h, 2, p, None, None, p, 1, 8, 8, None) == -1 and b"skip" in lib.danra_last_error()
+    assert lib.danra_instance_norm(p, p, 1, 1024, 48, None) == -1
+    assert lib.danra_conv1(h, p, p, p, p, p, 1, 40, 64, None) == -1 and b"multiples of 16" in lib.danra_last_error()
+    assert lib.danra_nchw_to_nhwc(p, None, 1, 64, 1024, None) == -1
