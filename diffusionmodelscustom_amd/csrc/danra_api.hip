@@ -65,6 +65,10 @@ struct AttnP {
 struct BlockP {
     ConvP c1, c2, sc;
     bool has_sc = false;
+    // Blocks with a 1x1 stride-2 shortcut: the shortcut reads exactly the centre tap of the 3x3 stride-2 conv1 window,
+    // so both are one implicit GEMM with 2*planes output columns (rows planes.. hold the shortcut weights in the
+    // centre tap's K columns and zeros elsewhere).  c1.w / c1.bias point at the first half of these.
+    float *w_both = nullptr, *b_both = nullptr;
 };
 struct DecP {
     float* wt = nullptr;  // [4*Cin][Cin]
@@ -305,11 +309,37 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
             BlockP& blk = h->blocks[L - 1][b];
             const std::string p = "encoder.layer" + std::to_string(L) + "." + std::to_string(b);
             const int stride = (b == 0 && L > 1) ? 2 : 1;
-            RC_TRY(pack_conv_bn(blk.c1, p + ".conv1.weight", p + ".bn1", inpl, planes, 3, stride, 1));
-            RC_TRY(pack_conv_bn(blk.c2, p + ".conv2.weight", p + ".bn2", planes, planes, 3, 1, 1));
             blk.has_sc = (b == 0 && (L > 1 || inpl != planes));
+            const bool both = blk.has_sc && stride == 2;
+            if (both) {  // conv1's packed rows are followed by the shortcut's rows; the two bias vectors likewise
+                blk.w_both = bp.take((size_t)2 * planes * inpl * 9);
+                blk.b_both = bp.take((size_t)2 * planes);
+            }
+            if (both) {
+                blk.c1.Cin = inpl; blk.c1.Cout = planes; blk.c1.KH = blk.c1.KW = 3; blk.c1.stride = stride; blk.c1.pad = 1;
+                blk.c1.w = blk.w_both;
+                blk.c1.bias = blk.b_both;
+                if (fill) {
+                    HIP_TRY(launch_bn_fold(src_of(h, p + ".bn1.weight"), src_of(h, p + ".bn1.bias"),
+                                           src_of(h, p + ".bn1.running_mean"), src_of(h, p + ".bn1.running_var"),
+                                           scratch_scale, blk.c1.bias, planes, st));
+                    HIP_TRY(launch_pack_conv(src_of(h, p + ".conv1.weight"), scratch_scale, blk.c1.w, planes, inpl, 3, 3, st));
+                }
+            } else {
+                RC_TRY(pack_conv_bn(blk.c1, p + ".conv1.weight", p + ".bn1", inpl, planes, 3, stride, 1));
+            }
+            RC_TRY(pack_conv_bn(blk.c2, p + ".conv2.weight", p + ".bn2", planes, planes, 3, 1, 1));
             if (blk.has_sc)
                 RC_TRY(pack_conv_bn(blk.sc, p + ".downsample.0.weight", p + ".downsample.1", inpl, planes, 1, stride, 0));
+            if (both && fill) {
+                const size_t K = (size_t)9 * inpl;
+                float* rows2 = blk.w_both + (size_t)planes * K;
+                HIP_TRY(hipMemsetAsync(rows2, 0, (size_t)planes * K * sizeof(float), st));
+                HIP_TRY(hipMemcpy2DAsync(rows2 + (size_t)4 * inpl, K * sizeof(float), blk.sc.w, (size_t)inpl * sizeof(float),
+                                         (size_t)inpl * sizeof(float), planes, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(blk.b_both + planes, blk.sc.bias, (size_t)planes * sizeof(float),
+                                       hipMemcpyDeviceToDevice, st));
+            }
             inpl = planes;
         }
     }
@@ -485,13 +515,15 @@ IGemmArgs blank_args() {
     return a;
 }
 
+// out2 != null: the weight matrix holds 2*Cout rows (see BlockP::w_both); the second Cout columns go to out2, bias only.
 int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int B, int Hi, int Wi, const float* res,
-             int relu, const float* tbias, const float* nmean, const float* nrstd, hipStream_t st) {
+             int relu, const float* tbias, const float* nmean, const float* nrstd, hipStream_t st, float* out2 = nullptr) {
     IGemmArgs a = blank_args();
     const int Ho = (Hi + 2 * c.pad - c.KH) / c.stride + 1, Wo = (Wi + 2 * c.pad - c.KW) / c.stride + 1;
     a.A = in; a.W = c.w; a.bias = c.bias; a.res = res; a.tbias = tbias; a.out = out;
     a.nmean = nmean; a.nrstd = nrstd; a.zeros = h->ws.zeros;
-    a.M = B * Ho * Wo; a.N = c.Cout; a.K = c.KH * c.KW * c.Cin;
+    a.M = B * Ho * Wo; a.N = out2 ? 2 * c.Cout : c.Cout; a.K = c.KH * c.KW * c.Cin;
+    a.out2 = out2; a.n_split = out2 ? c.Cout : 0;
     a.a_mode = A_CONV;
     a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
     a.ldr = c.Cout; a.act = relu ? ACT_RELU : ACT_NONE; a.tb_stride = h->tb_width; a.rows_per_img = Ho * Wo;
@@ -634,11 +666,16 @@ int run_layer(danra_handle_s* h, int level, const float* x, float* out, int B, i
         float* t1 = ws.rt[0];
         float* sc = ws.rt[1];
         float* dst = last ? out : ws.rt[2 + (b & 1)];
-        RC_TRY(run_conv(h, blk.c1, cur, t1, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st));
         const float* idn = cur;
-        if (blk.has_sc) {
-            RC_TRY(run_conv(h, blk.sc, cur, sc, B, Hc, Wc, nullptr, 0, nullptr, nullptr, nullptr, st));
+        if (blk.w_both) {  // conv1 and the shortcut in one launch
+            RC_TRY(run_conv(h, blk.c1, cur, t1, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st, sc));
             idn = sc;
+        } else {
+            RC_TRY(run_conv(h, blk.c1, cur, t1, B, Hc, Wc, nullptr, 1, nullptr, nullptr, nullptr, st));
+            if (blk.has_sc) {
+                RC_TRY(run_conv(h, blk.sc, cur, sc, B, Hc, Wc, nullptr, 0, nullptr, nullptr, nullptr, st));
+                idn = sc;
+            }
         }
         RC_TRY(run_conv(h, blk.c2, t1, dst, B, Ho, Wo, idn, 1, last ? tbias : nullptr, nullptr, nullptr, st));
         cur = dst;

@@ -29,8 +29,10 @@ struct IGemmArgs {
     const float* nrstd;
     const float* zeros;  // >= 16 bytes of zeros: what a convolution's padding taps read
     float* out;
+    float* out2;     // optional second output (ST_ROW only): columns n >= n_split go to out2[m*ldc + n - n_split], bias only
     float* partial;  // split-K slabs [ksplit][M][N]
     int M, N, K;
+    int n_split;     // with out2: first column of the second output (a multiple of 64)
     int lda;
     int ldw;  // row stride of W in floats; 0 = K
     int a_mode;

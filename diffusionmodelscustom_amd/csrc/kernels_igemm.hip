@@ -78,6 +78,7 @@ __device__ __forceinline__ float4 activate(int act, float4 v) {
 
 __device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias, int m, int n, int img) {
     v += bias;
+    if (p.out2 && n >= p.n_split) return v;  // second output: bias only
     if (p.res) v += p.res[(size_t)m * p.ldr + n];
     v = activate(p.act, v);
     if (p.tbias) v += p.tbias[(size_t)img * p.tb_stride + n];
@@ -438,7 +439,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int n = n0 + oc4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && p.ksplit <= 1) bv = *reinterpret_cast<const float4*>(p.bias + n);
-    const unsigned long long co = col_offset(p, n);
+    // columns from n_split on belong to the second output (same rows, its own column 0, bias only); BN divides
+    // n_split, so a workgroup's columns lie on one side
+    const bool second = p.out2 && n0 >= p.n_split;
+    float* const outp = second ? p.out2 : p.out;
+    const unsigned long long co = col_offset(p, second ? n - p.n_split : n);
 #pragma unroll
     for (int j = 0; j < BM / 16; ++j) {
         const int row = (tid >> 4) + 16 * j;
@@ -450,6 +455,10 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             continue;
         }
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (second) {
+            *reinterpret_cast<float4*>(outp + rowOff[row] + co) = v;
+            continue;
+        }
         if (p.res) {
             const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rowOut[row] * p.ldr + n);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)rowImg[row] * p.tb_stride + n);
             v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
         }
-        *reinterpret_cast<float4*>(p.out + rowOff[row] + co) = v;
+        *reinterpret_cast<float4*>(outp + rowOff[row] + co) = v;
     }
 }
 
@@ -484,7 +493,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float bias = p.bias ? p.bias[n + q] : 0.f;
-            p.out[ro + col_offset(p, n + q)] = finish(p, e[q], bias, m, n + q, img);
+            const bool second = p.out2 && n + q >= p.n_split;
+            (second ? p.out2 : p.out)[ro + col_offset(p, second ? n + q - p.n_split : n + q)] = finish(p, e[q], bias, m, n + q, img);
         }
     }
 }
@@ -942,8 +952,9 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
     if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
     if (a.a_mode == A_CONV && !a.zeros) return hipErrorInvalidValue;
+    if (a.out2 && (a.n_split <= 0 || a.n_split % BN || a.n_split >= a.N || a.st_mode != ST_ROW)) return hipErrorInvalidValue;
     if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
-        a.M >= 32768 && !a.tbias && !a.res) {
+        a.M >= 32768 && !a.tbias && !a.res && !a.out2) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
         const int tiles = (a.M + 31) / 32 * nsplit;
