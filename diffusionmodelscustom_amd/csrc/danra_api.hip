@@ -314,8 +314,6 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
             if (both) {  // conv1's packed rows are followed by the shortcut's rows; the two bias vectors likewise
                 blk.w_both = bp.take((size_t)2 * planes * inpl * 9);
                 blk.b_both = bp.take((size_t)2 * planes);
-            }
-            if (both) {
                 blk.c1.Cin = inpl; blk.c1.Cout = planes; blk.c1.KH = blk.c1.KW = 3; blk.c1.stride = stride; blk.c1.pad = 1;
                 blk.c1.w = blk.w_both;
                 blk.c1.bias = blk.b_both;
