@@ -463,7 +463,8 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
         ws.rstd2 = bp.take((size_t)B * 512);
         ws.eps = bp.take((size_t)B * H * W * h->cfg.out_channels);
         ws.eps_uncond = bp.take((size_t)B * H * W * h->cfg.out_channels);
-        ws.stats_part_floats = (size_t)1 << 19;
+        ws.stats_part_floats = (size_t)1 << 19;  // sliced statistics; the fused producer leaves 4 floats per output pixel
+        if (ws.stats_part_floats < (size_t)4 * B * H * W) ws.stats_part_floats = (size_t)4 * B * H * W;
         ws.stats_part = bp.take(ws.stats_part_floats);
         ws.partial_floats = (size_t)16 << 20;  // 64 MiB of split-K slabs
         ws.partial = bp.take(ws.partial_floats);
@@ -612,7 +613,8 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     if (ct_w && C != 64) return fail(DANRA_EINVAL, "fused transposed convolution needs a 64-channel block");
     if (C == 64 && (ff || ct_w)) {  // the row-local GEMMs behind the attention core of a 64-channel block run as one kernel
         HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, ct_w, ct_b,
-                                   ct_w ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W, st));
+                                   ct_w ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W,
+                                   ct_w ? ws.stats_part : nullptr, st));
         return DANRA_OK;
     }
     float* attended = ff ? ws.qkv : out;
@@ -704,8 +706,12 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
-    if (!up_ready) RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
-    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
+    if (!up_ready) {
+        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
+        HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
+    } else {  // the producer of ws.up left its statistics in slices of 32 samples
+        HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
+    }
     RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
     // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels)
     HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st, ws.pre,
@@ -717,8 +723,12 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
 int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st,
                     bool up_ready = false) {
     Workspace& ws = h->ws;
-    if (!up_ready) RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
-    HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
+    if (!up_ready) {
+        RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
+        HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
+    } else {
+        HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
+    }
     HIP_TRY(launch_final_conv(ws.up, ws.mean1, ws.rstd1, h->final_conv.w, h->final_conv.bias, eps_nchw, B, 2 * Hh, 2 * Ww,
                               64, h->cfg.out_channels, st));
     return DANRA_OK;

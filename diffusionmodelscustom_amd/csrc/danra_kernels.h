@@ -54,10 +54,12 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
 //   a = o Wo^T + bo + x;  with W1: a += GELU(LayerNorm(a) W1^T + b1) W2^T + b2 (LayerNorm affine folded into W1/b1);
 //   v = act(a);  with Wt ([256][64], rows (dy, dx, co)): the kernel-2 stride-2 transposed convolution that consumes v is
 //   applied as well and `out` is its [B][2*ct_H][2*ct_W][64] result (v itself is not stored); else out = v.
-// At least one of W1 and Wt must be given.
+// With Wt and `part` (M and ct_H*ct_W multiples of 32) the kernel also leaves the InstanceNorm statistics of its output in
+// slices: part[image][S = ct_H*ct_W/8][{mean, centred sum of squares}][64], 32 samples per slice, for
+// launch_in_stats_from_slices.  At least one of W1 and Wt must be given.
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                              float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream);
+                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream);
 
 // One input plane's share of the 8x8 stride-2 pad-3 stem: out = conv(x; Wt[64][8x8], row stride ldw) [+ res] [+ tbias[b]],
 // x: [B][H][W], out/res: [B][H/2][W/2][64]; H and W multiples of 16.
@@ -116,6 +118,9 @@ hipError_t launch_tbias_gather(SampleState* state, const float* table, const int
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
                            int C, hipStream_t stream, float* out = nullptr, const float* skip = nullptr,
                            const float* tbias = nullptr, int tb_stride = 0);
+// mean / rstd of B images x 64 channels from S equal slices of `count` samples each (part[b][s][{mean, m2}][64])
+hipError_t launch_in_stats_from_slices(const float* part, float* mean, float* rstd, int B, int S, int count,
+                                       hipStream_t stream);
 // out = (x - mean)*rstd [+ skip] [+ tbias[b][c]]
 hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip,
                            const float* tbias, int tb_stride, float* out, int B, int HW, int C, hipStream_t stream);

@@ -671,7 +671,8 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
                                                      const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W2, const float* __restrict__ b2,
                                                      const float* __restrict__ Wt, const float* __restrict__ bt,
-                                                     float* __restrict__ out, int M, int act, int ct_H, int ct_W) {
+                                                     float* __restrict__ out, int M, int act, int ct_H, int ct_W,
+                                                     float* __restrict__ part) {
     constexpr int LDK = 68;
     constexpr int NW = FF ? 3 : 1;             // 64x64 matrices of the chain
     constexpr int WROWS = NW * 64 + (CT ? 256 : 0);
@@ -818,6 +819,33 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
                 make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         const float4 bv = *reinterpret_cast<const float4*>(bts + nt * 32 + oc4);
         const int q = nt >> 1;
+        if (part) {
+            // InstanceNorm statistics of the transposed convolution's output, for its consumer: this tile is one slice
+            // (32 pixels of one image, tap q) of 32 channels; its mean and centred sum of squares (two passes over
+            // the tile, lanes l and l + 32 share a column) go to part[image][slice][{mean, m2}][64].
+            const int col = lane & 31, r0 = (lane >> 5) * 16;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += stage[(r0 + r) * LDO + col];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / 32.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = stage[(r0 + r) * LDO + col] - mu;
+                m2 += d * d;
+            }
+            m2 += __shfl_xor(m2, 32);
+            if (lane < 32) {
+                const int hw = ct_H * ct_W;
+                const int bimg = m0 / hw;
+                const int slice = ((m0 - bimg * hw) >> 5) * 4 + q;
+                const int S = (hw >> 5) * 4;
+                float* dst = part + ((size_t)bimg * S + slice) * 128 + (nt & 1) * 32 + col;
+                dst[0] = mu + bts[nt * 32 + col];
+                dst[64] = m2;
+            }
+        }
         const unsigned long long co = ((unsigned long long)(q >> 1) * 2 * ct_W + (q & 1)) * 64 + (nt & 1) * 32 + oc4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -831,8 +859,9 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
 template <bool FF, bool CT>
 static hipError_t launch_attn_tail64_t(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                                        const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                                       float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream) {
+                                       float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream) {
     const int tasks = (M + 31) / 32;
+    if (part && (!CT || M % 32 || (ct_H * ct_W) % 32)) return hipErrorInvalidValue;  // a slice = 32 rows of one image
     int waves = (FF && CT) ? 4 : 8;  // LDS budget; 4 also when there are few row tiles (fewer only stretch the staging)
     while (waves > 4 && tasks < 128 * waves) waves /= 2;
     const int wrows = (FF ? 3 : 1) * 64 + (CT ? 256 : 0);
@@ -843,16 +872,16 @@ static hipError_t launch_attn_tail64_t(const float* o, const float* x, const flo
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_attn_tail64<FF, CT>), dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x, Wo,
-                       bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W);
+                       bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part);
     return hipGetLastError();
 }
 
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                              float* out, int M, int act, int ct_H, int ct_W, hipStream_t stream) {
-    if (W1 && Wt) return launch_attn_tail64_t<true, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
-    if (W1) return launch_attn_tail64_t<true, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
-    if (Wt) return launch_attn_tail64_t<false, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, stream);
+                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream) {
+    if (W1 && Wt) return launch_attn_tail64_t<true, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, stream);
+    if (W1) return launch_attn_tail64_t<true, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, nullptr, stream);
+    if (Wt) return launch_attn_tail64_t<false, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, stream);
     return hipErrorInvalidValue;  // the plain output projection goes through launch_igemm
 }
 

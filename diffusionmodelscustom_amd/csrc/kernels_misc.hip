@@ -333,6 +333,54 @@ __global__ void k_in_stats_merge(const float* __restrict__ part, float* __restri
     rstd[i] = 1.0f / sqrtf(m2 / ((float)S * (float)HWslice) + 1e-5f);
 }
 
+// The same merge for many slices of 64 channels: one workgroup per image, lanes = channels (coalesced slice rows),
+// the four waves split the slices and meet in LDS twice (mean, then the centred sums).
+__global__ __launch_bounds__(256) void k_in_stats_merge64(const float* __restrict__ part, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int S, int count) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* src = part + (size_t)b * S * 128 + c;
+    float msum = 0.f;
+    for (int s0 = w; s0 < S; s0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) msum += (s0 + 4 * u < S) ? v[u] : 0.f;
+    }
+    red[w][c] = msum;
+    __syncthreads();
+    const float mu = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)S;
+    __syncthreads();
+    float m2 = 0.f;
+    for (int s0 = w; s0 < S; s0 += 32) {
+        float v[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+            q[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128 + 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float d = v[u] - mu;
+            m2 += (s0 + 4 * u < S) ? q[u] + (float)count * d * d : 0.f;
+        }
+    }
+    red[w][c] = m2;
+    __syncthreads();
+    if (w == 0) {
+        const float tot = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        mean[b * 64 + c] = mu;
+        rstd[b * 64 + c] = 1.0f / sqrtf(tot / ((float)S * (float)count) + 1e-5f);
+    }
+}
+
+hipError_t launch_in_stats_from_slices(const float* part, float* mean, float* rstd, int B, int S, int count,
+                                       hipStream_t stream) {
+    hipLaunchKernelGGL(k_in_stats_merge64, dim3(B), dim3(256), 0, stream, part, mean, rstd, S, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
                            int C, hipStream_t stream, float* out, const float* skip, const float* tbias, int tb_stride) {
     constexpr long min_blocks = 128;  // measured on MI355X: more slices than this cost more in the merge than they gain
