@@ -12,7 +12,7 @@ import zlib
 
 import torch
 
-__all__ = ["fill_state_dict_", "synthetic_state_dict", "synthetic_inputs"]
+__all__ = ["fill_state_dict_", "synthetic_state_dict", "synthetic_inputs", "SyntheticDANRADataset"]
 
 
 def _gen(name: str, seed: int) -> torch.Generator:
@@ -72,3 +72,35 @@ def synthetic_inputs(batch: int, height: int, width: int, seed: int = 42, condit
     lsm = (torch.rand(batch, 1, height, width, generator=g) < 0.45).float()
     topo = -12.0 + 342.0 * torch.rand(batch, 1, height, width, generator=g)
     return {"x": x, "y": y, "cond_img": cond, "lsm_cond": lsm, "topo_cond": topo}
+
+
+class SyntheticDANRADataset(torch.utils.data.Dataset):
+    """Items with the dict contract of the reference's cut-out dataset
+    (DDPM_DANRA_conditional_lumi/data_DANRA_conditional.py:513-564): ``img`` (the high-resolution truth, [1, H, W]),
+    ``classifier`` (season label, int64 scalar), ``img_cond`` (conditioning image), ``lsm``, ``sdf``, ``topo`` (cut-outs of
+    the static fields) and ``points`` (the cut-out corners), each key present only when the corresponding option is on,
+    as there.  Values are seeded synthetic fields (see ``synthetic_inputs``); nothing is read from disk."""
+
+    def __init__(self, n_samples: int, size: int, conditional_seasons=True, conditional_images=True, lsm_topo=True,
+                 sdf_weighted_loss=False, num_classes: int = 4, seed: int = 42):
+        self.n_samples, self.size, self.seed, self.num_classes = n_samples, size, seed, num_classes
+        self.conditional_seasons, self.conditional_images = conditional_seasons, conditional_images
+        self.lsm_topo, self.sdf_weighted_loss = lsm_topo, sdf_weighted_loss
+
+    def __len__(self):
+        return self.n_samples
+
+    def __getitem__(self, idx):
+        d = synthetic_inputs(1, self.size, self.size, seed=self.seed + 1000 * idx, num_classes=self.num_classes)
+        sample = {'img': d["x"][0]}
+        if self.conditional_images:
+            if self.conditional_seasons:
+                sample['classifier'] = d["y"][0]
+            sample['img_cond'] = d["cond_img"][0]
+        if self.lsm_topo:
+            sample['lsm'] = d["lsm_cond"][0]
+            if self.sdf_weighted_loss:
+                sample['sdf'] = torch.rand(1, self.size, self.size, generator=_gen("sdf", self.seed + idx))
+            sample['topo'] = d["topo_cond"][0]
+        sample['points'] = torch.tensor([0, self.size, 0, self.size])
+        return sample

@@ -279,3 +279,34 @@ def test_generation_files_have_the_reference_layout(tmp_path):
     gio.save_generation_samples(str(tmp_path), "u.npz", gen)
     back = gio.load_generation_samples(str(tmp_path), "u.npz")
     assert back["cond"] is None and back["season"] is None and np.array_equal(back["gen"], gen.numpy())
+
+
+def test_dataset_dict_contract_feeds_a_training_epoch():
+    """Batches with the reference dataset's dict keys (data_DANRA_conditional.py:513-564) go through one epoch of the
+    training step as the reference's pipeline arranges it (training_DANRA_conditional.py:775-984: keys -> positional model
+    arguments, sampleTimesteps, noiseImage, MSE on the predicted noise, optimiser step), here restated on this package."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    from diffusionmodelscustom_amd.synthetic import SyntheticDANRADataset
+    ds = SyntheticDANRADataset(4, 32, sdf_weighted_loss=True)
+    item = ds[0]
+    assert list(item) == ['img', 'classifier', 'img_cond', 'lsm', 'sdf', 'topo', 'points']
+    assert item['img'].shape == (1, 32, 32) and item['classifier'].dtype == torch.int64 and item['points'].shape == (4,)
+    assert list(SyntheticDANRADataset(1, 32, conditional_images=False, lsm_topo=False)[0]) == ['img', 'points']
+    model = build_model("cond", 32)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    du = DiffusionUtils(100, gs.BETA_MIN, gs.BETA_MAX, "cpu", "linear")
+    before = model.encoder.conv1.weight.detach().clone()
+    total = 0.0
+    for samples in torch.utils.data.DataLoader(ds, batch_size=2):
+        images = samples['img'].to(torch.float)
+        t = du.sampleTimesteps(images.shape[0])
+        x_t, noise = du.noiseImage(images, t)
+        opt.zero_grad()
+        pred = model(x_t, t, samples['classifier'], samples['img_cond'].to(torch.float), samples['lsm'].to(torch.float),
+                     samples['topo'].to(torch.float))
+        loss = torch.nn.functional.mse_loss(pred, noise)
+        loss.backward()
+        opt.step()
+        total += loss.item()
+    assert total == total and total > 0 and not torch.equal(before, model.encoder.conv1.weight)
