@@ -165,3 +165,20 @@ def test_other_head_counts(golden, dev, variant, heads):
         x = gs.randn(500, 1, 64, 64, 64)
         fn = cpu_ref.image_self_attention_clean if clean_net else cpu_ref.image_self_attention
         assert rel_err(ops.attention(0, x.to(dev)).cpu(), fn(sd, "encoder.attention_layers.0", x, heads)) < TOL_OP
+
+
+@pytest.mark.parametrize("variant", list(gs.CLEAN_VARIANTS))
+def test_full_batch_equals_single_image_evaluations(clean, dev, variant):
+    """Batch 64 takes the large-batch kernels (the attention tail fused with the next transposed convolution and its
+    statistics); batch 1 does not.  Images must not depend on the batch they are evaluated in."""
+    model = clean[variant][0]
+    inp = {k: None if v is None else v.to(dev) for k, v in gs.variant_inputs(variant, 64, 64, seed=77).items()}
+    t = (torch.arange(64, device=dev) * 13) % 999 + 1
+    pick = lambda v, i: None if v is None else v[i:i + 1]  # noqa: E731
+    with torch.no_grad():
+        full = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert torch.isfinite(full).all()
+        for i in (0, 31, 63):
+            one = model(inp["x"][i:i + 1], t[i:i + 1], pick(inp["y"], i), pick(inp["cond_img"], i),
+                        pick(inp["lsm_cond"], i), pick(inp["topo_cond"], i))
+            assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
