@@ -625,3 +625,18 @@ def test_per_op_entry_points_refuse_bad_arguments(cond64, dev):
     assert lib.danra_instance_norm(p, p, 1, 1024, 48, None) == -1
     assert lib.danra_conv1(h, p, p, p, p, p, 1, 40, 64, None) == -1 and b"multiples of 16" in lib.danra_last_error()
     assert lib.danra_nchw_to_nhwc(p, None, 1, 64, 1024, None) == -1
+
+
+def test_128x128_batch_32_equals_single_image_evaluations(dev):
+    """The 128x128 benchmark shape: at batch 32 both 64-channel decoder blocks hand their output to the next transposed
+    convolution inside one kernel (with its InstanceNorm slice statistics); at batch 1 neither does."""
+    model = build_model("cond", 128).to(dev)
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 32, 128, seed=3).items()}
+    t = (torch.arange(32, device=dev) * 31) % 999 + 1
+    with torch.no_grad():
+        full = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert torch.isfinite(full).all()
+        for i in (0, 17, 31):
+            one = model(inp["x"][i:i + 1], t[i:i + 1], inp["y"][i:i + 1], inp["cond_img"][i:i + 1],
+                        inp["lsm_cond"][i:i + 1], inp["topo_cond"][i:i + 1])
+            assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
