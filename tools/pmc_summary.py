@@ -1,0 +1,55 @@
+"""Summarise the two counter passes of tools/pmc_traffic.sh into the table kept as profiles/r01_pmc_traffic.txt and the
+flash-attention rows kept as profiles/r01_flash_traffic.json.
+
+    python tools/pmc_summary.py gpurun_out/pmc > profiles/r01_pmc_traffic.txt
+
+Counter unit: KiB.  gfx950 correction: FETCH_SIZE counts a 128-byte read request as 64 bytes, so reads = 2 x FETCH_SIZE;
+WRITE_SIZE is exact.  Median over the launches of each (kernel, grid size)."""
+import csv
+import json
+import os
+import re
+import statistics
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    rows = defaultdict(list)
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter or "danra::" not in r["Kernel_Name"]:
+                continue
+            name = re.sub(r"^(void )?danra::", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*$", "", name)
+            rows[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return rows
+
+
+def main():
+    base = sys.argv[1]
+    fetch = load(os.path.join(base, "fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+    write = load(os.path.join(base, "write", "w_counter_collection.csv"), "WRITE_SIZE")
+    print("# HBM-side traffic per launch, MI355X, conditional 64x64 at batch 64: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE")
+    print("# in separate passes (tools/pmc_traffic.sh; 11 denoise steps), summarised by tools/pmc_summary.py.  Counter unit: KiB.")
+    print("# gfx950 correction applied in the MiB columns: FETCH_SIZE counts 128-byte read requests as 64 bytes, so")
+    print("# reads = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Median over the launches of each (kernel, grid size).")
+    print(f"{'kernel':34s} {'grid threads':>12s} {'launches':>8s} {'FETCH_SIZE KiB':>15s} {'WRITE_SIZE KiB':>15s} {'read MiB':>9s} {'write MiB':>9s}")
+    keys = sorted(fetch, key=lambda k: -(2 * statistics.median(fetch[k]) + statistics.median(write.get(k, [0]))) * len(fetch[k]))
+    flash = {}
+    for k in keys:
+        f = statistics.median(fetch[k])
+        w = statistics.median(write.get(k, [0.0]))
+        print(f"{k[0]:34s} {k[1]:12d} {len(fetch[k]):8d} {f:15.1f} {w:15.1f} {2 * f / 1024:9.2f} {w / 1024:9.2f}")
+        if k[0].startswith("k_flash_hd16"):
+            flash[k[1]] = {"read_bytes": 2 * f * 1024, "write_bytes": w * 1024}
+    if len(sys.argv) > 2 and flash:
+        grids = sorted(flash, reverse=True)  # larger grid = L 1024, smaller = L 256 (batch 64, 4 heads)
+        out = {"k_flash_hd16": {"L1024_B64": flash[grids[0]], "L256_B64": flash[grids[-1]]},
+               "source": "tools/pmc_traffic.sh + tools/pmc_summary.py (FETCH_SIZE x2 on gfx950, WRITE_SIZE)"}
+        with open(sys.argv[2], "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
