@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict
 hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
                              float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
     if (Cin == 64 && W % 16 == 0) {
-        int R = 8;
+        int R = 8;  // measured at 64x64: 4 -> 21.6 us, 8 -> 20.7 us, 16 -> 32.3 us
         while (R > 1 && ((R + 2) * W > 1770 || H % R)) R /= 2;
         if ((R + 2) * W <= 1770 && H % R == 0) {
             const size_t lds2 = (9 * ((size_t)(R + 2) * W + 1) + 16) * sizeof(float);
