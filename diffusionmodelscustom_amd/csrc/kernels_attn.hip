@@ -715,6 +715,7 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
         if (hd == 32) return launch_flash_wide<2>(q, k, v, out, B, heads, L, stream);
         if (hd == 64) return launch_flash_wide<4>(q, k, v, out, B, heads, L, stream);
     }
+    if (L == 64 && hd == 128) return launch_flash_wide_qt<8, 1>(q, k, v, out, B, heads, L, stream);
     if (L <= 16 && hd > 128) {
         const float scale = 1.0f / sqrtf((float)hd);
         const dim3 grid(B * heads), block(64 * L);
