@@ -10,7 +10,7 @@ optional all-gather of the results after it.  Nothing is exchanged inside the de
 import torch
 import torch.distributed as dist
 
-__all__ = ["broadcast_model_", "shard_range", "shard_batch", "sample_sharded"]
+__all__ = ["broadcast_model_", "shard_range", "shard_batch", "sample_sharded", "sample_sharded_clean"]
 
 
 def _world():
@@ -72,6 +72,10 @@ def sample_sharded(diffusion, model, x, y=None, cond_img=None, lsm_cond=None, to
         local = diffusion.sample(xs, model, ys, cond_img=cs, lsm_cond=ls, topo_cond=ts)
     if not gather or world == 1:
         return local
+    return _gather_ragged(local, batch, world)
+
+
+def _gather_ragged(local, batch, world):
     widest = -(-batch // world)
     padded = local.new_zeros((widest,) + tuple(local.shape[1:]))
     padded[:local.shape[0]] = local
@@ -82,3 +86,24 @@ def sample_sharded(diffusion, model, x, y=None, cond_img=None, lsm_cond=None, to
         lo, hi = shard_range(batch, r, world)
         keep.append(part[:hi - lo])
     return torch.cat(keep, dim=0)
+
+
+def sample_sharded_clean(diffusion, model, n, channels_hr, y=None, cond_img=None, lsm_cond=None, topo_cond=None,
+                         cfg_scale=0.0, gather=True, host_noise=None, start_image=None):
+    """The same sharding for ``diffusion_modules.DiffusionUtils.sample(n, model, channels_hr, ...)`` (the sampler that
+    draws its own start image): this rank samples its slice of the ``n`` images with the matching slices of the
+    conditioning tensors.  Start images and noise come from each rank's own generator unless ``start_image`` /
+    ``host_noise`` (global tensors, sliced here) are given."""
+    rank, world = _world()
+    lo, hi = shard_range(n, rank, world)
+    ys, cs, ls, ts = shard_batch(rank, world, y, cond_img, lsm_cond, topo_cond)
+    if host_noise is not None or start_image is not None:
+        local = diffusion.sample_with_host_noise(
+            hi - lo, model, channels_hr, None if host_noise is None else host_noise[:, lo:hi],
+            start_image=None if start_image is None else start_image[lo:hi], y=ys, cond_img=cs, lsm_cond=ls,
+            topo_cond=ts, cfg_scale=cfg_scale)
+    else:
+        local = diffusion.sample(hi - lo, model, channels_hr, ys, cs, ls, ts, cfg_scale)
+    if not gather or world == 1:
+        return local
+    return _gather_ragged(local, n, world)

@@ -55,6 +55,18 @@ def _worker(rank, world, port, batch, out_dir):
     assert float((gathered - whole).abs().max() / whole.abs().max()) < 1e-5
     assert torch.equal(local, gathered[lo:hi])
     torch.save(gathered, os.path.join(out_dir, f"rank{rank}.pt"))
+
+    # the sampler that draws its own start image (clean-application call surface), guided, sharded the same way
+    from diffusionmodelscustom_amd import diffusion_modules as dm
+    from diffusionmodelscustom_amd.distributed import sample_sharded_clean
+    from model_util import build_clean_model
+    cmodel = build_clean_model("clean_class", 32)
+    cdu = dm.DiffusionUtils(T, 1e-4, 0.02, "cpu", "linear", img_size=32, data_scaled=True)
+    x0 = torch.randn(batch, 1, 32, 32, generator=g)
+    whole_c = cdu.sample_with_host_noise(batch, cmodel, 1, noise, start_image=x0, y=inp["y"], cfg_scale=2.0)
+    cmodel.eval()
+    got_c = sample_sharded_clean(cdu, cmodel, batch, 1, y=inp["y"], cfg_scale=2.0, host_noise=noise, start_image=x0)
+    assert got_c.shape == whole_c.shape and float((got_c - whole_c).abs().max() / whole_c.abs().max()) < 1e-5
     dist.barrier()
     dist.destroy_process_group()
 
