@@ -945,6 +945,32 @@ int danra_noise_image(const float* x, const int64_t* t, const float* alpha_hat, 
     return DANRA_OK;
 }
 
+static int check_core_shape(int B, int heads, int L, int head_dim) {
+    if (head_dim != 16)
+        return fail(DANRA_EINVAL, "head_dim %d: the differentiable attention core exists for head_dim 16 only", head_dim);
+    if (B <= 0 || heads <= 0 || L <= 0 || L % 128)
+        return fail(DANRA_EINVAL, "B=%d heads=%d L=%d: L must be a positive multiple of 128", B, heads, L);
+    if ((long long)B * heads * L >= (1LL << 27)) return fail(DANRA_EINVAL, "B*heads*L = %lld is too large", (long long)B * heads * L);
+    return DANRA_OK;
+}
+
+int danra_attention_core_fwd(const float* q, const float* k, const float* v, float* out, float* lse2, int B, int heads,
+                             int L, int head_dim, void* stream) {
+    if (!q || !k || !v || !out) return fail(DANRA_EINVAL, "null argument");
+    if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
+    HIP_TRY(launch_attention_hd16(q, k, v, out, lse2, B, heads, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_attention_core_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                             const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads, int L,
+                             int head_dim, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse2 || !dq || !dk || !dv || !delta) return fail(DANRA_EINVAL, "null argument");
+    if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
+    HIP_TRY(launch_attention_hd16_bwd(q, k, v, out, dout, lse2, dq, dk, dv, delta, B, heads, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,

@@ -70,6 +70,15 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads,
                             int L, int hd, hipStream_t stream);
+// head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
+// query's scaled scores in the exp2 domain, which the backward pass needs.
+hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
+                                 int heads, int L, hipStream_t stream);
+// Gradients of that forward: dout tokens [B][L][heads*16] -> dq, dk, dv [B*heads][L][16]; delta: [B*heads][L] scratch
+// (receives sum_d dout*out per query).  Two kernels, no atomics.
+hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                     const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads,
+                                     int L, hipStream_t stream);
 
 // ---------------------------------------------------------------- small kernels
 // Device-resident state of the sampling loop: one denoise step can be enqueued (or replayed from a

@@ -34,7 +34,8 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 template <int QT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
-                                                    int L, int heads, int n_bh, float scale_log2e) {
+                                                    float* __restrict__ LSE2, int L, int heads, int n_bh,
+                                                    float scale_log2e) {
     __shared__ __attribute__((aligned(16))) float Ks[2][KVT * KROW];
     __shared__ __attribute__((aligned(16))) float Vs[2][KVT * KROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,6 +207,8 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         const float inv = 1.0f / l;
         float4 o = make_float4(ot[t][0] * inv, ot[t][1] * inv, ot[t][2] * inv, ot[t][3] * inv);
         *reinterpret_cast<float4*>(O + ((size_t)b * L + q0 + t * 16 + lq) * C + head * 16 + 4 * g) = o;
+        // the row's log-sum-exp in the exp2 domain (reference + log2 of the sum), kept for the backward kernels
+        if (LSE2 != nullptr && g == 0) LSE2[(size_t)bh * L + q0 + t * 16 + lq] = log2f(l) - negm[t][0];
     }
 }
 
@@ -703,14 +706,18 @@ static hipError_t launch_attn_small(const float* q, const float* k, const float*
     return hipGetLastError();
 }
 
+hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
+                                 int heads, int L, hipStream_t stream) {
+    if (L % 128 != 0) return hipErrorInvalidValue;
+    const float scale_log2e = 0.25f * 1.4426950408889634f;
+    dim3 grid((L / 128) * B * heads);
+    hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
                             int hd, hipStream_t stream) {
-    if (hd == 16 && L % 128 == 0) {
-        const float scale_log2e = 0.25f * 1.4426950408889634f;
-        dim3 grid((L / 128) * B * heads);
-        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, L, heads, B * heads, scale_log2e);
-        return hipGetLastError();
-    }
+    if (hd == 16 && L % 128 == 0) return launch_attention_hd16(q, k, v, out, nullptr, B, heads, L, stream);
     if (L % 64 == 0 && L >= 256) {
         if (hd == 32) return launch_flash_wide<2>(q, k, v, out, B, heads, L, stream);
         if (hd == 64) return launch_flash_wide<4>(q, k, v, out, B, heads, L, stream);

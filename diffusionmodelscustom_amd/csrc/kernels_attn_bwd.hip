@@ -1,0 +1,259 @@
+// Backward pass of the head_dim-16 flash attention core (the training step's counterpart of k_flash_hd16).
+//
+// Forward, per (image, head):  S = (Q K^T) / 4,  P = softmax_rows(S),  O = P V.  k_flash_hd16 also leaves
+// LSE2[q] = log2(sum_k exp(S[q][k])) (the row's log-sum-exp in the exp2 domain), so that the backward kernels
+// rebuild any probability tile as P = exp2(S * log2(e) - LSE2) without a second softmax pass.
+//
+// Backward, with D[q] = sum_d dO[q][d] O[q][d]:
+//   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - D),   dQ = dS K / 4,   dK = dS^T Q / 4.
+//
+// Two kernels, no atomics, so the result is deterministic:
+//   k_flash_hd16_bwd_dq  - a wave owns 16*QT queries and walks the keys (the forward's structure): score tiles are
+//                          formed transposed (lane = query), -LSE2 and -D enter as the C operands of the matrix
+//                          products, dQ^T = K^T dS^T accumulates in registers.  It also writes D for the second kernel.
+//   k_flash_hd16_bwd_dkv - a wave owns 16*KT keys and walks the queries: score tiles are formed untransposed
+//                          (lane = key) so that the contraction of dV^T = dO^T P and dK^T = Q^T dS runs over the
+//                          register index, and dK / dV accumulate in registers.
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32) throughout: operand A lane (i, k-slot), operand B lane (j, k-slot),
+// result lane (j, g) holds rows 4g .. 4g+3 of column j.
+#include "danra_kernels.h"
+
+namespace danra {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BT = 64;    // rows of the streamed operand per LDS tile
+static constexpr int BROW = 20;  // padded LDS row (floats) of a 16-float row: conflict-free b32 column reads
+
+#define MFMA4(acc, a4, b4)                                                        \
+    do {                                                                          \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a4).x, (b4).x, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a4).y, (b4).y, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a4).z, (b4).z, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a4).w, (b4).w, acc, 0, 0, 0); \
+    } while (0)
+
+// Workgroup id -> (image*heads + head, block within it); all blocks of one (image, head) on one XCD (ids are dealt
+// round-robin over the 8 XCDs), so its streamed rows are fetched into one L2.
+__device__ __forceinline__ void decode_block(int id, int nblk, int n_bh, int& bh, int& blk) {
+    if (n_bh % 8 == 0) {
+        bh = (id / (8 * nblk)) * 8 + (id & 7);
+        blk = (id >> 3) % nblk;
+    } else {
+        bh = id / nblk;
+        blk = id - bh * nblk;
+    }
+}
+
+// Q, K, V, dQ: [n_bh][L][16];  O, dO: tokens [B][L][heads*16] at column head*16;  LSE2, Dout: [n_bh][L].
+template <int QT>
+__global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K,
+                                                           const float* __restrict__ V, const float* __restrict__ O,
+                                                           const float* __restrict__ dO, const float* __restrict__ LSE2,
+                                                           float* __restrict__ dQ, float* __restrict__ Dout, int L,
+                                                           int heads, int n_bh, float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) float Vs[2][BT * BROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bh, qblk;
+    decode_block(blockIdx.x, L / (4 * QT * 16), n_bh, bh, qblk);
+    const int q0 = qblk * (4 * QT * 16) + wave * (QT * 16);
+    const int lq = lane & 15, g = lane >> 4;
+    const int b = bh / heads, head = bh - b * heads, C = heads * 16;
+    const float scale_log2e = scale * 1.4426950408889634f;
+
+    const float* Qb = Q + (size_t)bh * L * 16;
+    const float* Kb = K + (size_t)bh * L * 16;
+    const float* Vb = V + (size_t)bh * L * 16;
+
+    // resident operands of the wave's queries: lane (q, g) holds columns 4g .. 4g+3 of row q
+    float4 qf[QT], dof[QT];
+    f32x4 neglse[QT], negd[QT], dq[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0 + t * 16 + lq;
+        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)q * 16 + 4 * g);
+        qf[t].x *= scale_log2e; qf[t].y *= scale_log2e; qf[t].z *= scale_log2e; qf[t].w *= scale_log2e;
+        const size_t tok = ((size_t)b * L + q) * C + head * 16 + 4 * g;
+        dof[t] = *reinterpret_cast<const float4*>(dO + tok);
+        const float4 of = *reinterpret_cast<const float4*>(O + tok);
+        float d = dof[t].x * of.x + dof[t].y * of.y + dof[t].z * of.z + dof[t].w * of.w;
+        d += __shfl_xor(d, 16);
+        d += __shfl_xor(d, 32);
+        if (g == 0) Dout[(size_t)bh * L + q] = d;
+        const float l2 = LSE2[(size_t)bh * L + q];
+        neglse[t] = f32x4{-l2, -l2, -l2, -l2};
+        negd[t] = f32x4{-d, -d, -d, -d};
+        dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int srow = tid >> 2, sc4 = (tid & 3) * 4;
+    float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
+    float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * 16 + sc4);
+    *reinterpret_cast<float4*>(&Ks[0][srow * BROW + sc4]) = kreg;
+    *reinterpret_cast<float4*>(&Vs[0][srow * BROW + sc4]) = vreg;
+    __syncthreads();
+
+    const int ntiles = L / BT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        {   // unconditional prefetch (the last tile re-reads itself)
+            const int nxt = min(kt + 1, ntiles - 1);
+            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * BT + srow) * 16 + sc4);
+            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * BT + srow) * 16 + sc4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // 16 keys at a time
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][(j * 16 + lq) * BROW + 4 * g]);
+            const float4 vf = *reinterpret_cast<const float4*>(&Vs[buf][(j * 16 + lq) * BROW + 4 * g]);
+            float kt4[4];  // K^T: lane (d, g) holds K[key 4g + r][d]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kt4[r] = Ks[buf][(j * 16 + 4 * g + r) * BROW + lq];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4 s = neglse[t], dp = negd[t];
+                MFMA4(s, kf, qf[t]);    // S^T log2(e) - LSE2 : lane (q, g) holds keys 4g .. 4g+3
+                MFMA4(dp, vf, dof[t]);  // dP^T - D
+                f32x4 ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dq[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt4[r], ds[r], dq[t], 0, 0, 0);
+            }
+        }
+        *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * BROW + sc4]) = kreg;
+        *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * BROW + sc4]) = vreg;
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float4 o = make_float4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+        *reinterpret_cast<float4*>(dQ + ((size_t)bh * L + q0 + t * 16 + lq) * 16 + 4 * g) = o;
+    }
+}
+
+// Q, K, V, dK, dV: [n_bh][L][16];  dO: tokens [B][L][heads*16];  LSE2, D: [n_bh][L].
+template <int KT>
+__global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, const float* __restrict__ dO,
+                                                            const float* __restrict__ LSE2, const float* __restrict__ D,
+                                                            float* __restrict__ dK, float* __restrict__ dV, int L,
+                                                            int heads, int n_bh, float scale) {
+    __shared__ __attribute__((aligned(16))) float Qs[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) float dOs[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) float NLs[2][BT];  // -LSE2 of the tile's queries
+    __shared__ __attribute__((aligned(16))) float NDs[2][BT];  // -D
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bh, kblk;
+    decode_block(blockIdx.x, L / (4 * KT * 16), n_bh, bh, kblk);
+    const int k0 = kblk * (4 * KT * 16) + wave * (KT * 16);
+    const int lq = lane & 15, g = lane >> 4;
+    const int b = bh / heads, head = bh - b * heads, C = heads * 16;
+    const float scale_log2e = scale * 1.4426950408889634f;
+
+    const float* Qb = Q + (size_t)bh * L * 16;
+    const float* dOb = dO + (size_t)b * L * C + head * 16;
+    const float* Lb = LSE2 + (size_t)bh * L;
+    const float* Db = D + (size_t)bh * L;
+
+    // resident operands of the wave's keys: lane (key, g) holds columns 4g .. 4g+3 of row key
+    float4 kf[KT], vf[KT];
+    f32x4 dk[KT], dv[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const size_t row = ((size_t)bh * L + k0 + t * 16 + lq) * 16 + 4 * g;
+        kf[t] = *reinterpret_cast<const float4*>(K + row);
+        kf[t].x *= scale_log2e; kf[t].y *= scale_log2e; kf[t].z *= scale_log2e; kf[t].w *= scale_log2e;
+        vf[t] = *reinterpret_cast<const float4*>(V + row);
+        dk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // staging: 64 queries x 16 floats of Q and dO (one float4 each per thread); -LSE2 and -D by the first 64 threads
+    const int srow = tid >> 2, sc4 = (tid & 3) * 4, r64 = tid & 63;
+    float4 qreg = *reinterpret_cast<const float4*>(Qb + (size_t)srow * 16 + sc4);
+    float4 doreg = *reinterpret_cast<const float4*>(dOb + (size_t)srow * C + sc4);
+    float lreg = Lb[r64], dreg = Db[r64];
+    *reinterpret_cast<float4*>(&Qs[0][srow * BROW + sc4]) = qreg;
+    *reinterpret_cast<float4*>(&dOs[0][srow * BROW + sc4]) = doreg;
+    if (tid < 64) {
+        NLs[0][r64] = -lreg;
+        NDs[0][r64] = -dreg;
+    }
+    __syncthreads();
+
+    const int ntiles = L / BT;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int buf = qt & 1;
+        {
+            const int nxt = min(qt + 1, ntiles - 1);
+            qreg = *reinterpret_cast<const float4*>(Qb + (size_t)(nxt * BT + srow) * 16 + sc4);
+            doreg = *reinterpret_cast<const float4*>(dOb + (size_t)(nxt * BT + srow) * C + sc4);
+            lreg = Lb[nxt * BT + r64];
+            dreg = Db[nxt * BT + r64];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // 16 queries at a time
+            const float4 qa = *reinterpret_cast<const float4*>(&Qs[buf][(j * 16 + lq) * BROW + 4 * g]);
+            const float4 doa = *reinterpret_cast<const float4*>(&dOs[buf][(j * 16 + lq) * BROW + 4 * g]);
+            const f32x4 nl = *reinterpret_cast<const f32x4*>(&NLs[buf][j * 16 + 4 * g]);  // -LSE2 of queries 4g .. 4g+3
+            const f32x4 nd = *reinterpret_cast<const f32x4*>(&NDs[buf][j * 16 + 4 * g]);
+            float qt4[4], dot4[4];  // Q^T, dO^T: lane (d, g) holds row (query 4g + r), column d
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qt4[r] = Qs[buf][(j * 16 + 4 * g + r) * BROW + lq];
+                dot4[r] = dOs[buf][(j * 16 + 4 * g + r) * BROW + lq];
+            }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                f32x4 s = nl, dp = nd;
+                MFMA4(s, qa, kf[t]);    // S log2(e) - LSE2 : lane (key, g) holds queries 4g .. 4g+3
+                MFMA4(dp, doa, vf[t]);  // dP - D
+                f32x4 p, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(s[r]);
+                    ds[r] = p[r] * dp[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dot4[r], p[r], dv[t], 0, 0, 0);
+                    dk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt4[r], ds[r], dk[t], 0, 0, 0);
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(&Qs[buf ^ 1][srow * BROW + sc4]) = qreg;
+        *reinterpret_cast<float4*>(&dOs[buf ^ 1][srow * BROW + sc4]) = doreg;
+        if (tid < 64) {
+            NLs[buf ^ 1][r64] = -lreg;
+            NDs[buf ^ 1][r64] = -dreg;
+        }
+        __syncthreads();
+    }
+
+    // lane (key, g) holds dK[key][4g .. 4g+3] and dV[key][4g .. 4g+3]
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const size_t row = ((size_t)bh * L + k0 + t * 16 + lq) * 16 + 4 * g;
+        *reinterpret_cast<float4*>(dK + row) = make_float4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+        *reinterpret_cast<float4*>(dV + row) = make_float4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+    }
+}
+
+hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                     const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads,
+                                     int L, hipStream_t stream) {
+    if (L % 128 != 0) return hipErrorInvalidValue;
+    const float scale = 0.25f;  // head_dim^-1/2
+    const dim3 grid((L / 128) * B * heads);
+    hipLaunchKernelGGL(k_flash_hd16_bwd_dq<2>, grid, dim3(256), 0, stream, q, k, v, o, dout, lse2, dq, delta, L, heads,
+                       B * heads, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flash_hd16_bwd_dkv<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
+                       B * heads, scale);
+    return hipGetLastError();
+}
+
+}  // namespace danra

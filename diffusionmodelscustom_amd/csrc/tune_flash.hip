@@ -18,10 +18,10 @@ static void run(const char* name, const float* q, const float* k, const float* v
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, L, heads, B * heads, sc);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e0, 0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, L, heads, B * heads, sc);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;

@@ -55,6 +55,9 @@ _SIGNATURES = {
                                            _P, ctypes.c_int, _P, _P]),
     "danra_noise_image": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_uint64, ctypes.c_uint64, _P]),
+    "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
@@ -164,6 +167,57 @@ def noise_image(x, t, alpha_hat, noise=None, seed=0, offset=0):
         for keep in (tt, ah):
             keep.record_stream(torch.cuda.current_stream())
     return noisy, z
+
+
+class _AttentionCoreHD16(torch.autograd.Function):
+    """softmax(q k^T / 4) v per head with head_dim 16, forward and backward in libdanra_hip.so
+    (danra_attention_core_fwd / _bwd): the L x L score matrices exist only in registers in either direction.
+    qkv: [3, B, heads, L, 16] contiguous -> tokens [B, L, heads*16]."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        lib = load_library()
+        _, B, heads, L, hd = qkv.shape
+        out = torch.empty((B, L, heads * hd), device=qkv.device, dtype=torch.float32)
+        lse2 = torch.empty((B * heads, L), device=qkv.device, dtype=torch.float32)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_core_fwd(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(out), _ptr(lse2), B,
+                                                     heads, L, hd, _stream()), "danra_attention_core_fwd")
+        ctx.save_for_backward(qkv, out, lse2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = load_library()
+        qkv, out, lse2 = ctx.saved_tensors
+        _, B, heads, L, hd = qkv.shape
+        dout = _f32(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse2)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_core_bwd(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(out), _ptr(dout),
+                                                     _ptr(lse2), _ptr(dqkv[0]), _ptr(dqkv[1]), _ptr(dqkv[2]), _ptr(delta),
+                                                     B, heads, L, hd, _stream()), "danra_attention_core_bwd")
+        return dqkv
+
+
+def attention_core_supported(tokens, n_heads):
+    """True when the differentiable self-attention of [B, L, C] `tokens` can run its core in the native library:
+    CUDA fp32 outside autocast, head_dim 16, L a multiple of 128 (the 64-channel levels of the 4-head network)."""
+    return (tokens.is_cuda and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and tokens.shape[-1] == 16 * n_heads and tokens.shape[1] % 128 == 0
+            and tokens.shape[0] * n_heads * tokens.shape[1] < (1 << 27))
+
+
+def differentiable_self_attention(mha, tokens):
+    """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module:
+    the two projections as torch ops (autograd handles them), the scaled-dot-product core in the native library."""
+    B, L, C = tokens.shape
+    heads = mha.num_heads
+    qkv = torch.nn.functional.linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
+    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous()
+    attended = _AttentionCoreHD16.apply(qkv)
+    return torch.nn.functional.linear(attended, mha.out_proj.weight, mha.out_proj.bias)
 
 
 class UNetEngine:

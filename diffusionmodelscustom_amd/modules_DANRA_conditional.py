@@ -46,6 +46,18 @@ class SinusoidalEmbedding(nn.Module):
         return torch.stack((torch.sin(arg), torch.cos(arg)), dim=-1).reshape(arg.shape[0], self.dim_size)
 
 
+def self_attention(mha: nn.MultiheadAttention, normed: torch.Tensor):
+    """``mha(normed, normed, normed, need_weights=False)[0]`` on the differentiable path.  On a CUDA fp32 tensor whose
+    heads are 16 wide and whose token count is a multiple of 128 (the 64-channel levels, where the L x L matrices
+    of torch's composition dominate a training step's time and memory) the scaled-dot-product core runs forward and
+    backward in ``libdanra_hip.so``; the library is then mandatory.  Everything else is torch's own module."""
+    if normed.is_cuda and mha.dropout == 0.0 and mha.batch_first and mha._qkv_same_embed_dim:
+        from . import hip_engine
+        if hip_engine.attention_core_supported(normed, mha.num_heads):
+            return hip_engine.differentiable_self_attention(mha, normed)
+    return mha(normed, normed, normed, need_weights=False)[0]
+
+
 class ImageSelfAttention(nn.Module):
     """LayerNorm -> multi-head self-attention over the H*W tokens -> + un-normalised input
     (reference modules:67-110)."""
@@ -61,7 +73,7 @@ class ImageSelfAttention(nn.Module):
         _, C, H, W = x.shape
         tokens = x.reshape(-1, C, H * W).permute(0, 2, 1)
         normed = self.layernorm(tokens)
-        attended, _ = self.attention(normed, normed, normed, need_weights=False)
+        attended = self_attention(self.attention, normed)
         return (attended + tokens).permute(0, 2, 1).reshape(-1, C, H, W)
 
 
@@ -150,6 +162,24 @@ class Encoder(ResNet):
         return fmap1, fmap2, fmap3, fmap4, fmap5
 
 
+class _DenseGradient(torch.autograd.Function):
+    """Identity whose backward hands on a contiguous gradient.
+
+    torch's CPU backward of ``instance_norm`` returns wrong values when the incoming gradient is laid out
+    [H][W][B][C] (observed with torch 2.10: relative error above 1 against the closed form, while a contiguous gradient
+    and the GPU kernel agree with it to 1e-7).  That layout is exactly what a ``batch_first`` MultiheadAttention sends
+    back through the token reshape of the attention block, which sits right behind the second InstanceNorm of a
+    decoder block, so a CPU training step of this network would silently use wrong gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad if grad.is_cuda or grad.is_contiguous() else grad.contiguous()
+
+
 class DecoderBlock(nn.Module):
     """convT(k2,s2) - IN - conv3x3 - IN - (+skip) - (+time bias, attention) - activation
     (reference modules:349-460)."""
@@ -181,6 +211,8 @@ class DecoderBlock(nn.Module):
 
     def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
         out = self.instance_norm2(self.conv(self.instance_norm1(self.transpose(fmap))))
+        if out.requires_grad:
+            out = _DenseGradient.apply(out)
         if torch.is_tensor(prev_fmap):
             assert (prev_fmap.shape == out.shape), self.shape_mismatch_message(prev_fmap, out)
             out = out + prev_fmap

@@ -44,8 +44,7 @@ class ImageSelfAttention(nn.Module):
         _, C, H, W = x.shape
         tokens = x.reshape(-1, C, H * W).permute(0, 2, 1)
         normed = self.layernorm(tokens)
-        attended, _ = self.mha(normed, normed, normed, need_weights=False)
-        attended = attended + tokens
+        attended = _base.self_attention(self.mha, normed) + tokens
         attended = attended + self.ff(attended)
         return attended.permute(0, 2, 1).reshape(-1, C, H, W)
 

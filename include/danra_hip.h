@@ -147,6 +147,23 @@ int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alp
                       float* noise_dev, int B, size_t per_image, int noise_mode, uint64_t seed, uint64_t offset,
                       void* stream);
 
+/* The scaled-dot-product core of ImageSelfAttention's nn.MultiheadAttention (modules_DANRA_conditional.py:100-104:
+ * softmax(q k^T / sqrt(head_dim)) v per head, dropout 0) for the TRAINING step (training_DANRA_conditional.py:963-984),
+ * where the in/out projections stay differentiable torch ops and this pair replaces the core's forward and its autograd
+ * backward without ever forming the L x L matrices.  head_dim must be 16 (the 64-channel levels of the 4-head network:
+ * L = 256 / 1024 at 64x64, 1024 / 4096 at 128x128) and L a multiple of 128, else DANRA_EINVAL.
+ * q, k, v: [B*heads][L][16] (projection outputs, head-split, unscaled); out: tokens [B][L][heads*16], head h at columns
+ * 16h..16h+15 (the layout out_proj consumes); lse2 (may be NULL when no backward follows): [B*heads][L], the
+ * log-sum-exp of every query's scaled scores in the exp2 domain. */
+int danra_attention_core_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, float* lse2_dev,
+                             int B, int heads, int L, int head_dim, void* stream);
+/* Gradients of danra_attention_core_fwd: dout_dev = dLoss/dout (layout of out) -> dq, dk, dv (layout of q, k, v).
+ * out_dev and lse2_dev are the forward's results; delta_dev: [B*heads][L] scratch.  Two kernels (one accumulates dq
+ * over the keys, one dk and dv over the queries), no atomics: results are deterministic. */
+int danra_attention_core_bwd(const float* q_dev, const float* k_dev, const float* v_dev, const float* out_dev,
+                             const float* dout_dev, const float* lse2_dev, float* dq_dev, float* dk_dev, float* dv_dev,
+                             float* delta_dev, int B, int heads, int L, int head_dim, void* stream);
+
 /* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
  * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns
  * it off), 0 enqueues every kernel of every step.  Both modes run the same kernels on the same data and

@@ -310,3 +310,42 @@ def test_dataset_dict_contract_feeds_a_training_epoch():
         opt.step()
         total += loss.item()
     assert total == total and total > 0 and not torch.equal(before, model.encoder.conv1.weight)
+
+
+def test_cpu_training_step_instance_norm_gradients_follow_closed_form():
+    """torch's CPU instance_norm backward is wrong for a gradient laid out [H][W][B][C], which is what the attention
+    block behind a decoder block's second InstanceNorm sends back; DecoderBlock hands the norm a contiguous gradient.
+    Every InstanceNorm of a CPU training step must reproduce the closed form
+    dx = (g - mean(g) - xhat * mean(g * xhat)) / sigma evaluated in float64."""
+    torch.manual_seed(11)
+    model = build_model()
+    model.train()
+    B = 2
+    x, target = torch.randn(B, 1, 64, 64), torch.randn(B, 1, 64, 64)
+    planes = [torch.randn(B, 1, 64, 64) for _ in range(3)]
+    worst = []
+
+    def watch(mod, inp, out):
+        if not torch.is_tensor(out) or out is inp[0]:
+            return
+        seen = {}
+        xin = inp[0]
+
+        def on_dx(dx):
+            xd, gd = xin.detach().double(), seen["g"].double()
+            mu = xd.mean((2, 3), keepdim=True)
+            sigma = (xd.var((2, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()
+            xh = (xd - mu) / sigma
+            closed = (gd - gd.mean((2, 3), keepdim=True) - xh * (gd * xh).mean((2, 3), keepdim=True)) / sigma
+            worst.append(((dx.double() - closed).abs().max() / closed.abs().max()).item())
+
+        xin.register_hook(on_dx)
+        out.register_hook(lambda g: seen.__setitem__("g", g.detach().clone()))
+
+    for blk in list(model.decoder.residual_layers) + [model.decoder.final_layer]:
+        blk.instance_norm1.register_forward_hook(watch)
+        blk.instance_norm2.register_forward_hook(watch)
+    pred = model(x, torch.tensor([17, 640]), torch.tensor([1, 3]), *planes)
+    torch.nn.functional.mse_loss(pred, target).backward()
+    assert len(worst) == 9
+    assert max(worst) < 5e-6, worst
