@@ -260,10 +260,15 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int fr = lane & 31;
     const int fh = (lane >> 5) * 4;
 
-    // Iteration `it` loads chunk c_begin+it into registers, multiplies chunk c_begin+it-1 from LDS
-    // buffer (it-1)&1 meanwhile, then writes the registers to buffer it&1.  One load site and one
-    // store site, so the staging registers stay in VGPRs; the final iteration's (clamped) reload is
-    // redundant by design: it keeps every load unconditional.
+    // Software pipeline over the chunks, one barrier per chunk.  Iteration `it` reads its operand fragments of chunk
+    // `it` from LDS buffer it&1 and issues the first k-block's matrix instructions; then it writes chunk it+1 (whose
+    // global loads were issued a whole iteration ago, so the wait for them is free) to buffer (it+1)&1 and issues the
+    // loads of chunk it+2; then the remaining matrix instructions and the barrier.  The staging work thus sits in the
+    // shadow of the wave's own matrix instructions, and between the last of them and the barrier there is nothing left
+    // to do.  (With the load wait and the LDS writes at the end of the iteration the 8x8 stride-2 convolution took
+    // 107 us in tune_igemm, with them at its start 99.5 us, in the middle 95 us; fragment reads ahead of the staging
+    // work: 109 us.)  One load site and one store site, so the staging registers stay in VGPRs; the loads past the
+    // last chunk re-read it (clamped): every load stays unconditional.
     const int n_chunks = c_end - c_begin;
     // conv: (kh, kw, cc) of the chunk being loaded, advanced incrementally (wave-uniform scalars)
     //       and delta = the tap's element offset inside the NHWC window, (kh*Wi + kw)*Cin + cc
@@ -281,12 +286,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int row_jump = (p.Wi - nkw) * p.Cin;   // from the box's last tap of a row to its first tap of the next
     const int wrow_jump = (p.KW - nkw) * p.Cin;
     const int kw_end = kw_lo + nkw;
-    for (int it = 0; it <= n_chunks; ++it) {
-        const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + it, c_end - 1) * BK;  // GEMM, stem
+
+    float4 araw[AR], amu[AR], ars[AR], breg[BR];
+    unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
+    int loaded = 0;       // chunks whose loads have been issued
+
+    // -- load phase: issue global loads only; nothing here may consume a loaded value
+    auto load_chunk = [&]() {
+        const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + loaded, c_end - 1) * BK;  // GEMM, stem
         const int wk_load = wk;
-        // -- load phase: issue global loads only; nothing here may consume a loaded value
-        float4 araw[AR], amu[AR], ars[AR], breg[BR];
-        unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
+        okmask = 0;
         if (GEMM) {
             // rows past M re-read row M-1: they only feed output rows that are never stored
 #pragma unroll
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                     ars[j] = *reinterpret_cast<const float4*>(rs);
                 }
             }
-            if (it + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (the final iteration re-reads the last one)
+            if (loaded + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (loads past the end re-read the last one)
                 t_cc += BK;
                 delta += BK;  // channels, then the next pixel of the row, are contiguous in NHWC
                 wk += BK;     // ... and in the [kh][kw][Cin] weight row
@@ -342,64 +351,87 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
+        ++loaded;
+    };
 
-        // keep the scheduler from hoisting the store phase's ALU (and with it the wait for the loads)
-        // above the matrix work
-        __builtin_amdgcn_sched_barrier(0);
-        if (it > 0 && !(dbg & 2)) {
-            const int buf = (it - 1) & 1;
-            const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
-            const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
+    // -- store phase: normalise / zero-fill the staged operand, then write it to LDS buffer `buf`
+    auto store_chunk = [&](int buf) {
+        float* As = As0 + buf * BM * LDK;
+        float* Bs = Bs0 + buf * BN * LDK;
 #pragma unroll
-            for (int kbi = 0; kbi < KB / KW; ++kbi) {
-                const int kb = kpart + kbi * KW;
-                const float4 a = *reinterpret_cast<const float4*>(As + kb * 8);
-                float4 b[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    // weights as the MFMA A operand: the product comes out transposed, so that a lane
-                    // owns runs of four consecutive output columns of one output row (16-byte epilogue)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].x, a.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].y, a.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].z, a.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t].w, a.w, acc[t], 0, 0, 0);
-                }
+        for (int j = 0; j < AR; ++j) {
+            float4 v = araw[j];
+            if (LNORM) {
+                v.x = (v.x - rmean[j]) * rrstd[j];
+                v.y = (v.y - rmean[j]) * rrstd[j];
+                v.z = (v.z - rmean[j]) * rrstd[j];
+                v.w = (v.w - rmean[j]) * rrstd[j];
             }
+            if (NORM) {
+                v.x = (v.x - amu[j].x) * ars[j].x;
+                v.y = (v.y - amu[j].y) * ars[j].y;
+                v.z = (v.z - amu[j].z) * ars[j].z;
+                v.w = (v.w - amu[j].w) * ars[j].w;
+            }
+            if (AMODE == A_CONV1) {
+                const unsigned m4 = okmask >> (4 * j);
+                v.x = (m4 & 1u) ? v.x : 0.f;
+                v.y = (m4 & 2u) ? v.y : 0.f;
+                v.z = (m4 & 4u) ? v.z : 0.f;
+                v.w = (m4 & 8u) ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
+    };
+
+    // -- matrix phase, in two parts: fetch this wave's operand fragments of the chunk in LDS buffer `buf` ...
+    constexpr int NKB = KB / KW;  // k-blocks of a chunk that this wave multiplies
+    float4 fa[NKB], fb[NKB][NT];
+    auto read_fragments = [&](int buf) {
+        const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
+        const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
+#pragma unroll
+        for (int kbi = 0; kbi < NKB; ++kbi) {
+            const int kb = kpart + kbi * KW;
+            fa[kbi] = *reinterpret_cast<const float4*>(As + kb * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fb[kbi][t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+        }
+    };
+    // ... and multiply them.  Weights are the MFMA A operand: the product comes out transposed, so that a lane owns
+    // runs of four consecutive output columns of one output row (16-byte epilogue).
+    auto multiply_fragment = [&](int kbi) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].x, fa[kbi].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].y, fa[kbi].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].z, fa[kbi].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].w, fa[kbi].w, acc[t], 0, 0, 0);
+        }
+    };
+
+    load_chunk();    // chunk 0
+    store_chunk(0);
+    load_chunk();    // chunk 1
+    __syncthreads();
+    for (int it = 0; it < n_chunks; ++it) {
+        if (!(dbg & 2)) {
+            read_fragments((dbg & 4) ? 0 : (it & 1));
+            multiply_fragment(0);
+        }
+        // the staging work sits between the first and the remaining matrix instructions of the wave
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) store_chunk((it + 1) & 1);  // chunk it+1 (in the last iteration a copy of the last chunk that nobody reads)
+        load_chunk();                               // chunk it+2
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int kbi = 1; kbi < NKB; ++kbi) multiply_fragment(kbi);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4) || it == 0) {   // -- store phase: normalise / zero-fill the staged operand, then write it to LDS
-            float* As = As0 + (it & 1) * BM * LDK;
-            float* Bs = Bs0 + (it & 1) * BN * LDK;
-#pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                float4 v = araw[j];
-                if (LNORM) {
-                    v.x = (v.x - rmean[j]) * rrstd[j];
-                    v.y = (v.y - rmean[j]) * rrstd[j];
-                    v.z = (v.z - rmean[j]) * rrstd[j];
-                    v.w = (v.w - rmean[j]) * rrstd[j];
-                }
-                if (NORM) {
-                    v.x = (v.x - amu[j].x) * ars[j].x;
-                    v.y = (v.y - amu[j].y) * ars[j].y;
-                    v.z = (v.z - amu[j].z) * ars[j].z;
-                    v.w = (v.w - amu[j].w) * ars[j].w;
-                }
-                if (AMODE == A_CONV1) {
-                    const unsigned m4 = okmask >> (4 * j);
-                    v.x = (m4 & 1u) ? v.x : 0.f;
-                    v.y = (m4 & 2u) ? v.y : 0.f;
-                    v.z = (m4 & 4u) ? v.z : 0.f;
-                    v.w = (m4 & 8u) ? v.w : 0.f;
-                }
-                *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
-            }
-#pragma unroll
-            for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
-        }
-        if (!(dbg & 4) || it == 0) __syncthreads();
+        if (!(dbg & 4)) __syncthreads();
     }
 
     // ---- sum the KW partial accumulators (fixed order: k-part 0, 1, 2, 3)
