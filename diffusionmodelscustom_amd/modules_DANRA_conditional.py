@@ -39,9 +39,18 @@ class SinusoidalEmbedding(nn.Module):
         self.dim_size = dim_size
         self.n = n
 
+    def divisors(self, device):
+        """n**(2i/dim) rounded to fp32, evaluated on the host as the reference does and kept per device (a host-to-device
+        copy per call would also be illegal while a training step is being captured into a graph)."""
+        cache = self.__dict__.setdefault('_div_cache', {})
+        key = (str(device), self.dim_size, self.n)
+        if key not in cache:
+            cache[key] = torch.tensor([self.n ** (2 * i / self.dim_size) for i in range(self.dim_size // 2)],
+                                      dtype=torch.float64).to(device=device, dtype=torch.float32)
+        return cache[key]
+
     def forward(self, x: torch.Tensor):
-        div = torch.tensor([self.n ** (2 * i / self.dim_size) for i in range(self.dim_size // 2)],
-                           dtype=torch.float64).to(device=x.device, dtype=torch.float32)
+        div = self.divisors(x.device)
         arg = x.reshape(-1).to(torch.float32)[:, None] / div[None, :]
         return torch.stack((torch.sin(arg), torch.cos(arg)), dim=-1).reshape(arg.shape[0], self.dim_size)
 
@@ -117,8 +126,11 @@ class Encoder(ResNet):
 
     def pos_encoding(self, t, channels):
         """[sin | cos] embedding, base 1000 (reference modules:203-211)."""
-        inv_freq = 1.0 / (1000 ** (torch.arange(0, channels, 2).float() / channels))
-        arg = t.repeat(1, channels // 2) * inv_freq.to(t.device)
+        cache = self.__dict__.setdefault('_inv_freq_cache', {})  # evaluated on the host (reference rounding), kept per device
+        key = (str(t.device), channels)
+        if key not in cache:
+            cache[key] = (1.0 / (1000 ** (torch.arange(0, channels, 2).float() / channels))).to(t.device)
+        arg = t.repeat(1, channels // 2) * cache[key]
         return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
 
     def make_time_projections(self, fmap_channels: Iterable[int]):

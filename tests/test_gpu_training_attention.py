@@ -179,3 +179,61 @@ def test_training_step_gradients(builder, monkeypatch):
     assert abs(loss - torch_loss) <= 1e-6 * abs(torch_loss) and abs(loss - cpu_loss) <= 1e-5 * abs(cpu_loss)
     compare(grads, torch_grads, 5e-3, "torch attention on the GPU")
     compare(grads, cpu_grads, 2e-2, "torch on the CPU")
+
+
+def test_graphed_train_step_equals_the_eager_loop_body():
+    """GraphedTrainStep (one captured hipGraph per training step) against the loop body written out
+    (reference training_DANRA_conditional.py:608-624), same timesteps and noise: same losses, same parameter changes after
+    three SGD steps; and building the object leaves the model as it was."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    from diffusionmodelscustom_amd.training import GraphedTrainStep, eager_train_step
+    torch.manual_seed(5)
+    B = 4
+    base = build_model()
+    base.train()
+    batches = []
+    for _ in range(3):
+        batches.append(dict(images=torch.randn(B, 1, 64, 64, device=DEV), seasons=torch.randint(0, 4, (B,), device=DEV),
+                            cond_images=torch.randn(B, 1, 64, 64, device=DEV), lsm=torch.rand(B, 1, 64, 64, device=DEV),
+                            topo=torch.randn(B, 1, 64, 64, device=DEV),
+                            t=torch.randint(1, 1000, (B,), device=DEV), noise=torch.randn(B, 1, 64, 64, device=DEV)))
+    du = DiffusionUtils(1000, 1e-4, 0.02, device=DEV)
+    lossfunc = torch.nn.MSELoss()
+
+    # plain SGD with momentum: the parameter change is then linear in the gradients (Adam's normalised update turns
+    # rounding-level differences of near-zero gradient entries into differences of the size of the learning rate)
+    eager = copy.deepcopy(base).to(DEV)
+    opt_e = torch.optim.SGD(eager.parameters(), lr=1e-2, momentum=0.9)
+    eager_losses = [eager_train_step(eager, opt_e, du, lossfunc, **b).item() for b in batches]
+
+    graphed = copy.deepcopy(base).to(DEV)
+    before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
+    opt_g = torch.optim.SGD(graphed.parameters(), lr=1e-2, momentum=0.9)
+    step = GraphedTrainStep(graphed, opt_g, du, lossfunc, batches[0], external_draws=True)
+    for k, v in graphed.state_dict().items():
+        assert torch.equal(v, before[k]), f"constructing the graphed step changed {k}"
+    graph_losses = [step(**b).item() for b in batches]
+
+    for a, b in zip(graph_losses, eager_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (graph_losses, eager_losses)
+    # what three steps did to every parameter, root-mean-square per tensor (single entries may differ completely where a
+    # pre-activation sits within rounding of a ReLU's kink, and torch's convolution weight gradients are not bitwise
+    # reproducible between runs)
+    se, sg = eager.state_dict(), graphed.state_dict()
+    moved = {k: (se[k] - before[k]).double() for k in se if se[k].dtype.is_floating_point and "running" not in k}
+    floor = 1e-2 * max(m.norm().item() / m.numel() ** 0.5 for m in moved.values())
+    for k, m in moved.items():
+        err = ((sg[k] - before[k]).double() - m).norm().item() / m.numel() ** 0.5
+        ref = max(m.norm().item() / m.numel() ** 0.5, floor)
+        assert err <= 2e-2 * ref, f"{k}: the graphed steps moved it differently (rms {err:.3e} against {ref:.3e})"
+    with pytest.raises(RuntimeError):
+        step(**{**batches[0], "images": batches[0]["images"][:2]})
+
+    # draws made inside the graph: every replay sees new timesteps and noise
+    opt_i = torch.optim.AdamW(graphed.parameters(), lr=1e-4, capturable=True)
+    with pytest.raises(RuntimeError):
+        GraphedTrainStep(graphed, torch.optim.AdamW(graphed.parameters(), lr=1e-4), du, lossfunc, batches[0])
+    inner = GraphedTrainStep(graphed, opt_i, du, lossfunc, {k: v for k, v in batches[0].items() if k not in ("t", "noise")})
+    b0 = {k: v for k, v in batches[0].items() if k not in ("t", "noise")}
+    losses = [inner(**b0).item() for _ in range(4)]
+    assert all(l == l and l > 0 for l in losses) and len(set(losses)) > 1, losses

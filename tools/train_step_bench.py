@@ -41,7 +41,7 @@ def time_steps(model, data, du, steps, warmup):
         loss = torch.nn.functional.mse_loss(model(noisy, t, y, *planes), noise)
         loss.backward()
         opt.step()
-        return loss
+        return loss.detach()
 
     for _ in range(warmup):
         one()
@@ -103,6 +103,26 @@ def main():
     ms, gib, loss = time_steps(model, data, du, a.steps, a.warmup)
     out["native_attention_core"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
                                     "peak_GiB": round(gib, 2), "last_loss": loss}
+    # the same step replayed from one hipGraph (diffusionmodelscustom_amd.training.GraphedTrainStep)
+    from diffusionmodelscustom_amd.training import GraphedTrainStep
+    model = build(a.size, dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True)
+    x, y, planes = data
+    step = GraphedTrainStep(model, opt, du, torch.nn.MSELoss(), dict(images=x, seasons=y, cond_images=planes[0],
+                                                                     lsm=planes[1], topo=planes[2]))
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(a.warmup):
+        step(x, y, *planes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(x, y, *planes)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    out["native_attention_core_graphed"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
+                                            "peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                                            "last_loss": float(loss)}
+    del step, opt, model
     real = hip_engine.attention_core_supported
     hip_engine.attention_core_supported = lambda *args: False
     try:
