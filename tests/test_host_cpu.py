@@ -349,3 +349,29 @@ def test_cpu_training_step_instance_norm_gradients_follow_closed_form():
     torch.nn.functional.mse_loss(pred, target).backward()
     assert len(worst) == 9
     assert max(worst) < 5e-6, worst
+
+
+def test_eager_train_step_is_the_reference_loop_body_and_graphing_needs_a_gpu():
+    """training.eager_train_step = the seven statements of the reference's loop body
+    (training_DANRA_conditional.py:608-624); with the draws given it is reproducible.  GraphedTrainStep refuses CPU
+    tensors and optimizers that cannot be captured."""
+    from diffusionmodelscustom_amd.training import GraphedTrainStep, eager_train_step
+    torch.manual_seed(2)
+    B = 2
+    batch = dict(images=torch.randn(B, 1, 32, 32), t=torch.tensor([5, 150]), noise=torch.randn(B, 1, 32, 32))
+    du = DiffusionUtils(200, 1e-4, 0.02)
+    results = []
+    for _ in range(2):
+        model = build_model("uncond", 32)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        loss = eager_train_step(model, opt, du, nn.MSELoss(), **batch)
+        results.append((loss.item(), model.decoder.final_layer.conv.weight.detach().clone()))
+    assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
+    model = build_model("uncond", 32)
+    model.train()
+    x_t, noise = du.noiseImage(batch["images"], batch["t"], batch["noise"])
+    by_hand = nn.MSELoss()(model(x_t, batch["t"], None, None, None, None), noise)
+    assert abs(by_hand.item() - results[0][0]) <= 1e-6 * abs(by_hand.item())
+    with pytest.raises(RuntimeError, match="CUDA"):
+        GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-2), du, nn.MSELoss(), batch)
