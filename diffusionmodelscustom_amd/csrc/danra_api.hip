@@ -515,8 +515,11 @@ IGemmArgs blank_args() {
 }
 
 // out2 != null: the weight matrix holds 2*Cout rows (see BlockP::w_both); the second Cout columns go to out2, bias only.
+// slabs != null: if the convolution is split over K, its reduction kernel is left out and *slabs describes the slabs
+// (the caller's next kernel sums them); slabs->count stays 0 when the convolution was not split and `out` is complete.
 int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int B, int Hi, int Wi, const float* res,
-             int relu, const float* tbias, const float* nmean, const float* nrstd, hipStream_t st, float* out2 = nullptr) {
+             int relu, const float* tbias, const float* nmean, const float* nrstd, hipStream_t st, float* out2 = nullptr,
+             InSlabs* slabs = nullptr) {
     IGemmArgs a = blank_args();
     const int Ho = (Hi + 2 * c.pad - c.KH) / c.stride + 1, Wo = (Wi + 2 * c.pad - c.KW) / c.stride + 1;
     a.A = in; a.W = c.w; a.bias = c.bias; a.res = res; a.tbias = tbias; a.out = out;
@@ -532,6 +535,16 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     a.batch = B;
     if (c.Cin % 32 || c.Cout % 64) return fail(DANRA_EINVAL, "conv channels %d->%d unsupported", c.Cin, c.Cout);
     choose_split(a, h->ws);
+    if (slabs) {
+        slabs->count = 0;
+        if (a.ksplit > 1 && !res && !relu && !tbias && !out2) {
+            a.keep_slabs = 1;
+            slabs->count = a.ksplit;
+            slabs->stride = (size_t)a.M * a.N;
+            slabs->bias = c.bias;
+            slabs->pix_major = a.pix_major;
+        }
+    }
     HIP_TRY(launch_igemm(a, st));
     return DANRA_OK;
 }
@@ -712,10 +725,14 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     } else {  // the producer of ws.up left its statistics in slices of 32 samples
         HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
     }
-    RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st));
-    // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels)
-    HIP_TRY(launch_in_stats(ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cout, st, ws.pre,
-                            skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width));
+    // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels);
+    // when the convolution is split over K and an image fits one block, that pass also sums the convolution's slabs
+    InSlabs slabs{0, 0, nullptr, 0};
+    RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st, nullptr,
+                    H2 * W2 <= 1024 ? &slabs : nullptr));
+    HIP_TRY(launch_in_stats(slabs.count ? ws.partial : ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B,
+                            H2 * W2, d.Cout, st, ws.pre, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width,
+                            slabs.count ? &slabs : nullptr));
     RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2));
     return DANRA_OK;
 }

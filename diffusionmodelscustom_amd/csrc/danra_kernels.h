@@ -46,6 +46,7 @@ struct IGemmArgs {
     int pix_major, batch;          // convolutions: rows ordered pixel-major (m = pixel*batch + image) when pix_major != 0
     int ksplit, chunks_per_split;  // chunks are counted 32-deep
     int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
+    int keep_slabs;                // split-K only: leave the slabs in `partial` (no reduction kernel); the consumer sums them
     int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
@@ -124,9 +125,18 @@ hipError_t launch_tbias_gather(SampleState* state, const float* table, const int
 // `part`: scratch of part_floats floats for sliced statistics (may be null: one block per image and 32 channels)
 // With `out` != null the normalised tensor (+ skip, + tbias[b][c]) is written as well (one fused pass when an
 // image's pixels fit a block's registers, statistics + k_in_apply otherwise).
+// `slabs` (unsliced launches only, i.e. HW <= 1024): x is not one tensor but the split-K slabs of the GEMM that produces
+// it - value = slab[0] + slab[1] + ... (in that order) + bias[c], each slab `stride` floats after the previous one,
+// rows in the GEMM's order (pixel-major: row = pixel * B + image) - so the reduction kernel of that GEMM is not needed.
+struct InSlabs {
+    int count;          // number of slabs (>= 2)
+    size_t stride;      // floats between slabs (M * N of the GEMM)
+    const float* bias;  // [C] or null
+    int pix_major;      // row order of the GEMM
+};
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
                            int C, hipStream_t stream, float* out = nullptr, const float* skip = nullptr,
-                           const float* tbias = nullptr, int tb_stride = 0);
+                           const float* tbias = nullptr, int tb_stride = 0, const InSlabs* slabs = nullptr);
 // mean / rstd of B images x 64 channels from S equal slices of `count` samples each (part[b][s][{mean, m2}][64])
 hipError_t launch_in_stats_from_slices(const float* part, float* mean, float* rstd, int B, int S, int count,
                                        hipStream_t stream);

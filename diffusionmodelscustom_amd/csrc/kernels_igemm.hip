@@ -1067,7 +1067,7 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
 #undef DANRA_LAUNCH_IGEMM
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (ks > 1) {
+    if (ks > 1 && !a.keep_slabs) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;

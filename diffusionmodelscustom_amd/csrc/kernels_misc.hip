@@ -226,7 +226,9 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
                                                   float* __restrict__ rstd, float* __restrict__ part, int HWtotal,
                                                   int C, float* __restrict__ out, const float* __restrict__ skip,
-                                                  const float* __restrict__ tbias, int tb_stride) {
+                                                  const float* __restrict__ tbias, int tb_stride, int n_slabs,
+                                                  size_t slab_stride, const float* __restrict__ slab_bias,
+                                                  size_t img_stride, size_t pix_stride) {
     __shared__ float4 red[32];
     const int b = blockIdx.x;
     const int c0 = blockIdx.y * 32;
@@ -235,10 +237,26 @@ __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, f
     const int slot = tid >> 3;
     const int S = gridDim.z;
     const int HW = HWtotal / S;  // <= 32 * NP
-    const float* base = x + ((size_t)b * HWtotal + (size_t)blockIdx.z * HW) * C + c0 + cq;
+    // input pixel p of image b sits at x[b * img_stride + p * pix_stride + c] (a plain NHWC tensor: HWtotal*C and C)
+    const float* base = x + (size_t)b * img_stride + (size_t)blockIdx.z * HW * pix_stride + c0 + cq;
     float4 v[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(base + (size_t)min(slot + 32 * i, HW - 1) * C);
+    for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(base + (size_t)min(slot + 32 * i, HW - 1) * pix_stride);
+    if (n_slabs > 1) {  // x = the split-K slabs of the producing GEMM: sum them in slab order, then the bias
+        for (int z = 1; z < n_slabs; ++z) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const float4 o = *reinterpret_cast<const float4*>(base + (size_t)z * slab_stride +
+                                                                  (size_t)min(slot + 32 * i, HW - 1) * pix_stride);
+                v[i].x += o.x; v[i].y += o.y; v[i].z += o.z; v[i].w += o.w;
+            }
+        }
+        if (slab_bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(slab_bias + c0 + cq);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { v[i].x += bv.x; v[i].y += bv.y; v[i].z += bv.z; v[i].w += bv.w; }
+        }
+    }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -382,7 +400,8 @@ hipError_t launch_in_stats_from_slices(const float* part, float* mean, float* rs
 }
 
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
-                           int C, hipStream_t stream, float* out, const float* skip, const float* tbias, int tb_stride) {
+                           int C, hipStream_t stream, float* out, const float* skip, const float* tbias, int tb_stride,
+                           const InSlabs* slabs) {
     constexpr long min_blocks = 128;  // measured on MI355X: more slices than this cost more in the merge than they gain
     // a block holds at most 1024 pixels x 32 channels in registers; more slices only while the grid is
     // small and the slices stay equal and at least 64 pixels long
@@ -398,11 +417,21 @@ hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part
         return launch_in_apply(x, mean, rstd, skip, tbias, tb_stride, out, B, HW, C, stream);
     }
     if (S > 1 && (!part || (size_t)B * S * 2 * C > part_floats)) return hipErrorInvalidValue;
+    if (slabs && (S > 1 || slabs->count < 2)) return hipErrorInvalidValue;
     const int per = (HW / S + 31) / 32;
     const dim3 grid(B, C / 32, S);
-    if (per <= 2) hipLaunchKernelGGL(k_in_stats<2>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
-    else if (per <= 8) hipLaunchKernelGGL(k_in_stats<8>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
-    else hipLaunchKernelGGL(k_in_stats<32>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride);
+    const int n_slabs = slabs ? slabs->count : 1;
+    const size_t slab_stride = slabs ? slabs->stride : 0;
+    const float* slab_bias = slabs ? slabs->bias : nullptr;
+    const bool pm = slabs && slabs->pix_major;
+    const size_t img_stride = pm ? (size_t)C : (size_t)HW * C, pix_stride = pm ? (size_t)B * C : (size_t)C;
+#define DANRA_IN_STATS(NP_)                                                                                            \
+    hipLaunchKernelGGL(k_in_stats<NP_>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride, \
+                       n_slabs, slab_stride, slab_bias, img_stride, pix_stride)
+    if (per <= 2) DANRA_IN_STATS(2);
+    else if (per <= 8) DANRA_IN_STATS(8);
+    else DANRA_IN_STATS(32);
+#undef DANRA_IN_STATS
     if (S > 1)
         hipLaunchKernelGGL(k_in_stats_merge, dim3((B * C + 255) / 256), dim3(256), 0, stream, part, mean, rstd, B * C, C, S,
                            HW / S);
