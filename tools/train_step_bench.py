@@ -91,13 +91,21 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels-last", action="store_true", help="parameters and activations in torch.channels_last")
     a = ap.parse_args()
+    if a.channels_last:
+        global build
+        plain_build = build
+
+        def build(size, dev):
+            return plain_build(size, dev).to(memory_format=torch.channels_last)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     d = synthetic_inputs(a.batch, a.size, a.size, seed=42, conditional=True)
     data = (d["x"].to(dev), d["y"].to(dev), [d["cond_img"].to(dev), d["lsm_cond"].to(dev), d["topo_cond"].to(dev)])
     du = DiffusionUtils(1000, 1e-4, 0.02, device=dev)
-    out = {"workload": f"DANRA conditional {a.size}x{a.size} training step (forward + MSE + backward + AdamW), batch {a.batch}, fp32",
+    out = {"workload": f"DANRA conditional {a.size}x{a.size} training step (forward + MSE + backward + AdamW), batch {a.batch}, fp32"
+                       + (", channels_last" if a.channels_last else ""),
            "steps": a.steps}
     model = build(a.size, dev)
     ms, gib, loss = time_steps(model, data, du, a.steps, a.warmup)
