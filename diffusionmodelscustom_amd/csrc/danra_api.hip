@@ -988,6 +988,49 @@ int danra_attention_core_bwd(const float* q, const float* k, const float* v, con
     return DANRA_OK;
 }
 
+int danra_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                              float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
+                              float momentum, int relu, void* stream) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return fail(DANRA_EINVAL, "running_mean and running_var go together");
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * HW < 2 || (long long)B * C * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, at least two values per channel, "
+                    "fewer than 2^31 elements", B, C, HW);
+    HIP_TRY(launch_bn_train_fwd(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, B, C, HW, eps, momentum,
+                                relu ? 1 : 0, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                              const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                              void* stream) {
+    if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || (relu && !y))
+        return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * C * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", B, C, HW);
+    HIP_TRY(launch_bn_train_bwd(x, dy, y, gamma, save_mean, save_rstd, dx, dgamma, dbeta, B, C, HW, relu ? 1 : 0,
+                                (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_instancenorm_fwd(const float* x, float* y, float* save_mean, float* save_rstd, int planes, int HW, float eps,
+                           void* stream) {
+    if (!x || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");
+    if (planes <= 0 || HW <= 0 || HW % 4 || (long long)planes * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "planes=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", planes, HW);
+    HIP_TRY(launch_in_train_fwd(x, y, save_mean, save_rstd, planes, HW, eps, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_instancenorm_bwd(const float* x, const float* dy, const float* save_mean, const float* save_rstd, float* dx,
+                           int planes, int HW, void* stream) {
+    if (!x || !dy || !save_mean || !save_rstd || !dx) return fail(DANRA_EINVAL, "null argument");
+    if (planes <= 0 || HW <= 0 || HW % 4 || (long long)planes * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "planes=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", planes, HW);
+    HIP_TRY(launch_in_train_bwd(x, dy, save_mean, save_rstd, dx, planes, HW, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,

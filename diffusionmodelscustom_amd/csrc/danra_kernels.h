@@ -154,6 +154,23 @@ hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alp
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 
+// ---------------------------------------------------------------- training step
+// BatchNorm2d in train mode on NCHW fp32 (HW a multiple of 4): batch statistics, optional fused ReLU; save_mean / save_rstd
+// [C] feed the backward pass; running_mean / running_var (may be null) are updated with `momentum` (unbiased variance).
+hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                               float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
+                               float momentum, int relu, hipStream_t stream);
+// y is the forward's output (read only with relu, for the mask)
+hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                               const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                               hipStream_t stream);
+
+// InstanceNorm2d(affine=False) on NCHW fp32, `planes` = B*C planes of HW values (HW a multiple of 4), with its backward
+hipError_t launch_in_train_fwd(const float* x, float* y, float* save_mean, float* save_rstd, int planes, int HW, float eps,
+                               hipStream_t stream);
+hipError_t launch_in_train_bwd(const float* x, const float* dy, const float* save_mean, const float* save_rstd, float* dx,
+                               int planes, int HW, hipStream_t stream);
+
 // ---------------------------------------------------------------- weight packing
 hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                           float* scale, float* shift, int C, hipStream_t stream);

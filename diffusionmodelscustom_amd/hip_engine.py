@@ -17,6 +17,10 @@ _lib_lock = threading.Lock()
 NOISE_HOST = 0
 NOISE_PHILOX = 1
 
+# The kernels of the differentiable path (attention core, train-mode BatchNorm, InstanceNorm: forward and backward).
+# False sends that path through torch's own operators everywhere - for comparisons; the inference path is not affected.
+native_training_kernels = True
+
 
 class DanraConfig(ctypes.Structure):
     _fields_ = [
@@ -58,6 +62,12 @@ _SIGNATURES = {
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
+    "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, _P]),
+    "danra_batchnorm_train_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, _P]),
+    "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
+    "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
@@ -204,7 +214,7 @@ class _AttentionCoreHD16(torch.autograd.Function):
 def attention_core_supported(tokens, n_heads):
     """True when the differentiable self-attention of [B, L, C] `tokens` can run its core in the native library:
     CUDA fp32 outside autocast, head_dim 16, L a multiple of 128 (the 64-channel levels of the 4-head network)."""
-    return (tokens.is_cuda and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
+    return (native_training_kernels and tokens.is_cuda and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
             and tokens.shape[-1] == 16 * n_heads and tokens.shape[1] % 128 == 0
             and tokens.shape[0] * n_heads * tokens.shape[1] < (1 << 27))
 
@@ -218,6 +228,97 @@ def differentiable_self_attention(mha, tokens):
     qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous()
     attended = _AttentionCoreHD16.apply(qkv)
     return torch.nn.functional.linear(attended, mha.out_proj.weight, mha.out_proj.bias)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in train mode (+ optional ReLU) on a contiguous NCHW fp32 CUDA tensor, forward and backward in
+    libdanra_hip.so (danra_batchnorm_train_fwd / _bwd).  The running statistics are updated in place by the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        lib = load_library()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        save_rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_batchnorm_train_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean),
+                                                      _ptr(save_rstd), _ptr(running_mean), _ptr(running_var), B, C, H * W,
+                                                      ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _stream()),
+                   "danra_batchnorm_train_fwd")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, y if relu else None, gamma, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        x, y, gamma, save_mean, save_rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _f32(dy, "dy")
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_batchnorm_train_bwd(_ptr(x), _ptr(dy), _ptr(y), _ptr(gamma), _ptr(save_mean),
+                                                      _ptr(save_rstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, H * W,
+                                                      int(ctx.relu), _stream()), "danra_batchnorm_train_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batchnorm_train_supported(bn, x):
+    """True when `bn(x)` in train mode can run in the native library: affine BatchNorm2d with running statistics and a
+    fixed momentum, on a contiguous NCHW fp32 CUDA tensor outside autocast whose H*W is a multiple of 4."""
+    return (native_training_kernels and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled()
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 2 and x.numel() < (1 << 31))
+
+
+def batchnorm_train(bn, x, relu=False):
+    """bn(x) [then ReLU] for a train-mode nn.BatchNorm2d through the native kernels (see batchnorm_train_supported)."""
+    with torch.no_grad():
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                                 float(bn.momentum), bool(relu))
+
+
+class _InstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine=False) on a contiguous NCHW fp32 CUDA tensor, forward and backward in libdanra_hip.so
+    (danra_instancenorm_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = load_library()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        save_rstd = torch.empty(B * C, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_instancenorm_fwd(_ptr(x), _ptr(y), _ptr(save_mean), _ptr(save_rstd), B * C, H * W,
+                                                   ctypes.c_float(eps), _stream()), "danra_instancenorm_fwd")
+        ctx.save_for_backward(x, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        x, save_mean, save_rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _f32(dy, "dy")
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_instancenorm_bwd(_ptr(x), _ptr(dy), _ptr(save_mean), _ptr(save_rstd), _ptr(dx), B * C,
+                                                   H * W, _stream()), "danra_instancenorm_bwd")
+        return dx, None
+
+
+def instance_norm(module, x):
+    """`module(x)`; an nn.InstanceNorm2d without affine parameters or running statistics on a contiguous NCHW fp32 CUDA
+    tensor (H*W a multiple of 4, outside autocast) runs forward and backward in the native library."""
+    if (native_training_kernels and type(module) is torch.nn.InstanceNorm2d and not module.affine and not module.track_running_stats and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled()
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.numel() < (1 << 31)):
+        return _InstanceNorm.apply(x, float(module.eps))
+    return module(x)
 
 
 class UNetEngine:

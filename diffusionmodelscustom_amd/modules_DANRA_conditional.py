@@ -19,7 +19,7 @@ from typing import Iterable, Optional
 import torch
 import torch.nn as nn
 
-from .resnet import BasicBlock, ResNet
+from .resnet import BasicBlock, ResNet, norm_relu
 
 __all__ = ["SinusoidalEmbedding", "ImageSelfAttention", "Encoder", "DecoderBlock", "Decoder", "DiffusionNet",
            "ResNet", "BasicBlock", "torch", "nn", "Optional", "Iterable"]
@@ -166,7 +166,7 @@ class Encoder(ResNet):
             return self.attention_layers[level](fmap)
 
         fmap1 = stage(0, self.conv1(x))
-        h = self.relu(self.bn1(self.conv2(fmap1)))
+        h = norm_relu(self.bn1, self.relu, self.conv2(fmap1))
         fmap2 = stage(1, self.layer1(h))
         fmap3 = stage(2, self.layer2(fmap2))
         fmap4 = stage(3, self.layer3(fmap3))
@@ -222,7 +222,12 @@ class DecoderBlock(nn.Module):
         return 'feature maps must be of same shape'
 
     def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
-        out = self.instance_norm2(self.conv(self.instance_norm1(self.transpose(fmap))))
+        up = self.transpose(fmap)
+        if up.is_cuda:  # the two norms run forward and backward in the native library where it has them
+            from .hip_engine import instance_norm
+            out = instance_norm(self.instance_norm2, self.conv(instance_norm(self.instance_norm1, up)))
+        else:
+            out = self.instance_norm2(self.conv(self.instance_norm1(up)))
         if out.requires_grad:
             out = _DenseGradient.apply(out)
         if torch.is_tensor(prev_fmap):

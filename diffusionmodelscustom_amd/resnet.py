@@ -8,7 +8,18 @@ initialisation, and the block arithmetic for the autograd path.  No torchvision 
 """
 import torch.nn as nn
 
-__all__ = ["BasicBlock", "ResNet"]
+__all__ = ["BasicBlock", "ResNet", "norm_relu"]
+
+
+def norm_relu(bn, relu, x):
+    """``relu(bn(x))`` (``relu`` None: just ``bn(x)``).  A train-mode BatchNorm2d on a CUDA fp32 tensor runs - with the
+    ReLU fused in - forward and backward in ``libdanra_hip.so``; everything else is the two torch modules."""
+    if x.is_cuda and type(bn) is nn.BatchNorm2d and bn.training:
+        from . import hip_engine
+        if hip_engine.batchnorm_train_supported(bn, x):
+            return hip_engine.batchnorm_train(bn, x, relu is not None)
+    y = bn(x)
+    return y if relu is None else relu(y)
 
 
 class BasicBlock(nn.Module):
@@ -27,9 +38,14 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        if self.downsample is None:
+            shortcut = x
+        elif isinstance(self.downsample, nn.Sequential) and len(self.downsample) == 2:
+            shortcut = norm_relu(self.downsample[1], None, self.downsample[0](x))
+        else:
+            shortcut = self.downsample(x)
+        y = norm_relu(self.bn1, self.relu, self.conv1(x))
+        y = norm_relu(self.bn2, None, self.conv2(y))
         return self.relu(y + shortcut)
 
 

@@ -164,6 +164,29 @@ int danra_attention_core_bwd(const float* q_dev, const float* k_dev, const float
                              const float* dout_dev, const float* lse2_dev, float* dq_dev, float* dk_dev, float* dv_dev,
                              float* delta_dev, int B, int heads, int L, int head_dim, void* stream);
 
+/* nn.BatchNorm2d in TRAIN mode (the encoder's bn1 and the BasicBlocks' bn1 / bn2 / downsample.1 after model.train(),
+ * training_DANRA_conditional.py:517; modules_DANRA_conditional.py:271 and torchvision's BasicBlock.forward): batch
+ * statistics per channel over (B, H, W), y = (x - mean) / sqrt(var_biased + eps) * gamma + beta, optionally followed by the
+ * ReLU that every such norm of the network except bn2 is followed by; running_mean / running_var (may both be NULL) move by
+ * `momentum` towards the batch mean / unbiased batch variance.  x, y: NCHW fp32 [B][C][HW] contiguous, HW a multiple
+ * of 4; save_mean / save_rstd: [C], kept for the backward pass. */
+int danra_batchnorm_train_fwd(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                              float* save_mean_dev, float* save_rstd_dev, float* running_mean_dev, float* running_var_dev,
+                              int B, int C, int HW, float eps, float momentum, int relu, void* stream);
+/* Its autograd backward: dy -> dx, dgamma, dbeta.  y_dev (the forward's output) is read only when relu != 0. */
+int danra_batchnorm_train_bwd(const float* x_dev, const float* dy_dev, const float* y_dev, const float* gamma_dev,
+                              const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dgamma_dev,
+                              float* dbeta_dev, int B, int C, int HW, int relu, void* stream);
+
+/* nn.InstanceNorm2d(affine=False) as the decoder blocks use it (modules_DANRA_conditional.py:412,419) on NCHW fp32 with
+ * its autograd backward, for the training step: `planes` = B*C planes of HW contiguous values each (HW a multiple of 4);
+ * y = (x - mean) / sqrt(var_biased + eps) per plane; save_mean / save_rstd: [planes], kept for the backward pass
+ * (dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat))). */
+int danra_instancenorm_fwd(const float* x_dev, float* y_dev, float* save_mean_dev, float* save_rstd_dev, int planes, int HW,
+                           float eps, void* stream);
+int danra_instancenorm_bwd(const float* x_dev, const float* dy_dev, const float* save_mean_dev, const float* save_rstd_dev,
+                           float* dx_dev, int planes, int HW, void* stream);
+
 /* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
  * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns
  * it off), 0 enqueues every kernel of every step.  Both modes run the same kernels on the same data and

@@ -237,3 +237,73 @@ def test_graphed_train_step_equals_the_eager_loop_body():
     b0 = {k: v for k, v in batches[0].items() if k not in ("t", "noise")}
     losses = [inner(**b0).item() for _ in range(4)]
     assert all(l == l and l > 0 for l in losses) and len(set(losses)) > 1, losses
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 64, 16, 16), True), ((3, 128, 8, 8), False), ((2, 512, 2, 2), True),
+                                        ((5, 64, 32, 32), False)])
+def test_batchnorm_train_kernels_match_torch(shape, relu):
+    """danra_batchnorm_train_fwd / _bwd against nn.BatchNorm2d in train mode (+ ReLU) evaluated in float64 on the CPU:
+    output, running statistics after two calls, input / weight / bias gradients."""
+    torch.manual_seed(21)
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    x1, x2 = torch.randn(shape) * 2 + 0.7, torch.randn(shape) - 0.3
+    dy = torch.randn(shape)
+
+    ref = copy.deepcopy(bn).double().train()
+    ref(x1.double())
+    xr = x2.double().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy.double())
+
+    gpu = copy.deepcopy(bn).to(DEV).train()
+    assert hip_engine.batchnorm_train_supported(gpu, x1.to(DEV))
+    hip_engine.batchnorm_train(gpu, x1.to(DEV), relu)
+    xg = x2.to(DEV).requires_grad_(True)
+    yg = hip_engine.batchnorm_train(gpu, xg, relu)
+    yg.backward(dy.to(DEV))
+    close(yg.detach().cpu(), yr.detach(), 1e-5, "output")
+    close(xg.grad.cpu(), xr.grad, 1e-5, "input gradient")
+    close(gpu.weight.grad.cpu(), ref.weight.grad, 1e-5, "weight gradient")
+    close(gpu.bias.grad.cpu(), ref.bias.grad, 1e-5, "bias gradient")
+    close(gpu.running_mean.cpu(), ref.running_mean, 1e-6, "running_mean")
+    close(gpu.running_var.cpu(), ref.running_var, 1e-6, "running_var")
+    assert int(gpu.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
+def test_train_mode_network_uses_the_native_batchnorm(monkeypatch):
+    model = build_model().to(DEV)
+    model.train()
+    fwd = count_calls(monkeypatch, "danra_batchnorm_train_fwd")
+    bwd = count_calls(monkeypatch, "danra_batchnorm_train_bwd")
+    B = 2
+    x = torch.randn(B, 1, 64, 64, device=DEV)
+    planes = [torch.randn(B, 1, 64, 64, device=DEV) for _ in range(3)]
+    model(x, torch.tensor([3, 900], device=DEV), torch.tensor([0, 2], device=DEV), *planes).square().mean().backward()
+    # the network has 20 such norms (bn1, 8 blocks x 2, 3 shortcut norms); those whose input arrives channels-last strided
+    # (a convolution fed by an attention block's output) stay with torch
+    assert len(fwd) == len(bwd) and 10 <= len(fwd) <= 20, (len(fwd), len(bwd))
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 4, 4), (3, 64, 32, 32), (2, 64, 128, 128), (5, 128, 8, 8)])
+def test_instance_norm_kernels_match_torch(shape):
+    """danra_instancenorm_fwd / _bwd against nn.InstanceNorm2d evaluated in float64 on the CPU."""
+    torch.manual_seed(31)
+    norm = torch.nn.InstanceNorm2d(shape[1])
+    x = torch.randn(shape) * 3 + 1
+    dy = torch.randn(shape)
+    xr = x.double().requires_grad_(True)
+    yr = norm(xr)
+    yr.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    yg = hip_engine.instance_norm(norm, xg)
+    assert yg.grad_fn is not None and "InstanceNorm" in type(yg.grad_fn).__name__
+    yg.backward(dy.to(DEV))
+    close(yg.detach().cpu(), yr.detach(), 1e-5, "output")
+    close(xg.grad.cpu(), xr.grad, 1e-5, "input gradient")

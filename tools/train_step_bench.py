@@ -1,6 +1,6 @@
 """Training-step timing on one GPU: forward + MSE loss + backward + AdamW step of the conditional DANRA network in train
-mode, with the 64-channel attention cores in libdanra_hip.so against torch's own nn.MultiheadAttention on the same
-device, and the attention core alone (forward, backward) against its algorithmic FLOPs.
+mode, with the attention cores, train-mode BatchNorm and InstanceNorm in libdanra_hip.so against torch's own operators on the
+same device, and the attention core alone (forward, backward) against its algorithmic FLOPs.
 
     python tools/train_step_bench.py [--size 64] [--batch 32] [--steps 10]
 
@@ -109,7 +109,7 @@ def main():
            "steps": a.steps}
     model = build(a.size, dev)
     ms, gib, loss = time_steps(model, data, du, a.steps, a.warmup)
-    out["native_attention_core"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
+    out["native_kernels"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
                                     "peak_GiB": round(gib, 2), "last_loss": loss}
     # the same step replayed from one hipGraph (diffusionmodelscustom_amd.training.GraphedTrainStep)
     from diffusionmodelscustom_amd.training import GraphedTrainStep
@@ -127,21 +127,20 @@ def main():
         loss = step(x, y, *planes)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
-    out["native_attention_core_graphed"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
+    out["native_kernels_graphed"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
                                             "peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                                             "last_loss": float(loss)}
     del step, opt, model
-    real = hip_engine.attention_core_supported
-    hip_engine.attention_core_supported = lambda *args: False
+    hip_engine.native_training_kernels = False   # the same step with torch's own attention / BatchNorm / InstanceNorm
     try:
         model = build(a.size, dev)
         ms, gib, loss = time_steps(model, data, du, a.steps, a.warmup)
-        out["torch_attention"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
-                                  "peak_GiB": round(gib, 2), "last_loss": loss}
+        out["all_torch"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
+                            "peak_GiB": round(gib, 2), "last_loss": loss}
     except torch.OutOfMemoryError as e:
-        out["torch_attention"] = {"error": "out of memory: " + str(e)[:80]}
+        out["all_torch"] = {"error": "out of memory: " + str(e)[:80]}
     finally:
-        hip_engine.attention_core_supported = real
+        hip_engine.native_training_kernels = True
     L = (a.size // 2) ** 2
     out["core_alone"] = {f"B{a.batch}_heads4_L{L}": time_core(a.batch, 4, L)}
     print(json.dumps(out))
