@@ -31,7 +31,7 @@ def run(size, batch, replays):
         torch.cuda.synchronize()
 
 
-def summarise(path, top):
+def summarise(path, top, sequence=False):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the replays run the same kernel sequence: the last replay = the shortest tail that repeats the tail before it
@@ -53,6 +53,16 @@ def summarise(path, top):
     print(f"last replay: {len(last)} kernels, busy {busy / 1e3:.0f} us, wall {(ends[-1] - starts[cut]) / 1e3:.0f} us")
     for name, (ns, n) in sorted(total.items(), key=lambda kv: -kv[1][0])[:top]:
         print(f"{ns / 1e3:9.1f} us  x{n:<4d} {100 * ns / busy:5.1f} %  {name}")
+    if sequence:   # the replay's kernels in launch order, runs of one name collapsed
+        print("--- launch order")
+        run_name, run_n = None, 0
+        for r in last + [None]:
+            name = None if r is None else r["Kernel_Name"][:70]
+            if name != run_name:
+                if run_name is not None:
+                    print(f"  x{run_n:<4d} {run_name}")
+                run_name, run_n = name, 0
+            run_n += 1
 
 
 if __name__ == "__main__":
@@ -62,8 +72,9 @@ if __name__ == "__main__":
     ap.add_argument("--replays", type=int, default=4)
     ap.add_argument("--trace")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--sequence", action="store_true")
     a = ap.parse_args()
     if a.trace:
-        summarise(a.trace, a.top)
+        summarise(a.trace, a.top, a.sequence)
     else:
         run(a.size, a.batch, a.replays)
