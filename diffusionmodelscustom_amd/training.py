@@ -129,4 +129,8 @@ class GraphedTrainStep:
                 raise RuntimeError(f"'{k}' has shape {tuple(src.shape)}, the captured step was built for {tuple(dst.shape)}")
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay rewrites parameters and buffers in place without touching their version counters, which is what
+        # DiffusionNet watches to know when its packed inference weights are stale: say so explicitly
+        if hasattr(self.model, "_hip_signature"):
+            self.model._hip_signature = None
         return self.loss

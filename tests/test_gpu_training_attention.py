@@ -212,6 +212,11 @@ def test_graphed_train_step_equals_the_eager_loop_body():
     step = GraphedTrainStep(graphed, opt_g, du, lossfunc, batches[0], external_draws=True)
     for k, v in graphed.state_dict().items():
         assert torch.equal(v, before[k]), f"constructing the graphed step changed {k}"
+    graphed.eval()
+    with torch.no_grad():   # packs the inference weights as they are BEFORE training
+        graphed(batches[0]["images"], batches[0]["t"], batches[0]["seasons"], batches[0]["cond_images"], batches[0]["lsm"],
+                batches[0]["topo"])
+    graphed.train()
     graph_losses = [step(**b).item() for b in batches]
 
     for a, b in zip(graph_losses, eager_losses):
@@ -228,6 +233,17 @@ def test_graphed_train_step_equals_the_eager_loop_body():
         assert err <= 2e-2 * ref, f"{k}: the graphed steps moved it differently (rms {err:.3e} against {ref:.3e})"
     with pytest.raises(RuntimeError):
         step(**{**batches[0], "images": batches[0]["images"][:2]})
+
+    # sampling after graphed steps sees the trained weights (the replay changes them without version bumps)
+    graphed.eval()
+    with torch.no_grad():
+        b0 = batches[0]
+        args = (b0["images"], b0["t"], b0["seasons"], b0["cond_images"], b0["lsm"], b0["topo"])
+        native = graphed(*args)
+        composed = graphed.decoder(*graphed.encoder(args[0], t=args[1], y=args[2], cond_img=args[3], lsm_cond=args[4],
+                                                    topo_cond=args[5]), t=args[1])
+    close(native.cpu(), composed.cpu(), 1e-4, "inference after graphed training steps")
+    graphed.train()
 
     # draws made inside the graph: every replay sees new timesteps and noise
     opt_i = torch.optim.AdamW(graphed.parameters(), lr=1e-4, capturable=True)
