@@ -743,6 +743,11 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
     if (!up_ready) {
         RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
         HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
+    } else if (final_conv_merges_slices(2 * Hh, 2 * Ww, 64)) {
+        // the producer of ws.up left its statistics in slices of 32 samples; the convolution merges them itself
+        HIP_TRY(launch_final_conv(ws.up, nullptr, nullptr, h->final_conv.w, h->final_conv.bias, eps_nchw, B, 2 * Hh, 2 * Ww,
+                                  64, h->cfg.out_channels, st, ws.stats_part, Hh * Ww / 8, 32));
+        return DANRA_OK;
     } else {
         HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
     }

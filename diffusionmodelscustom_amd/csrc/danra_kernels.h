@@ -144,8 +144,12 @@ hipError_t launch_in_stats_from_slices(const float* part, float* mean, float* rs
 hipError_t launch_in_apply(const float* x, const float* mean, const float* rstd, const float* skip,
                            const float* tbias, int tb_stride, float* out, int B, int HW, int C, hipStream_t stream);
 // 3x3 pad-1 conv Cin -> Cout (Cout <= 4) with InstanceNorm on load, NHWC in, NCHW out.
+// With `part` (only where final_conv_merges_slices says so) the statistics are not read from mean / rstd but merged in
+// the kernel from S slices of `count` samples each, part[image][S][{mean, m2}][64] (see launch_in_stats_from_slices).
+bool final_conv_merges_slices(int H, int W, int Cin);
 hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
-                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream,
+                             const float* part = nullptr, int S = 0, int count = 0);
 hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
                               size_t n, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
 // noisy = sqrt(alpha_hat[t_b]) * x + sqrt(1 - alpha_hat[t_b]) * z; z read from `noise` or drawn (and written there)

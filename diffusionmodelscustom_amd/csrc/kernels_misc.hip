@@ -530,17 +530,63 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
-                                                         int W, int Cout, int R) {
+                                                         int W, int Cout, int R, const float* __restrict__ part, int S,
+                                                         int count) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int P = (R + 2) * W;  // pixels of the strip incl. halo rows
     const int PS = P + 1;       // plane stride (odd: spreads the nine planes over the banks)
     float* Gs = sm;             // [9][PS]
     float* wcs = sm + 9 * PS;   // [16]
+    float* stat = wcs + 16;     // [2][64]: this image's mean and 1/std when they are formed here; scratch [4][64] = Gs
     const int b = blockIdx.y;
     const int y0 = blockIdx.x * R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, g = lane >> 4;
     const float* xb = x + (size_t)b * H * W * 64;
+    if (part) {
+        // The statistics arrive as S equal slices of `count` samples (part[image][S][{mean, m2}][64], left by the kernel
+        // that produced x): merge them here, with the arithmetic of k_in_stats_merge64, instead of in a kernel of its own
+        // (every strip of the image repeats the merge: S * 512 bytes from L2).
+        float* red = Gs;  // [4][64]
+        const int c = tid & 63, w4 = tid >> 6;
+        const float* src = part + (size_t)b * S * 128 + c;
+        float msum = 0.f;
+        for (int s0 = w4; s0 < S; s0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) msum += (s0 + 4 * u < S) ? v[u] : 0.f;
+        }
+        red[w4 * 64 + c] = msum;
+        __syncthreads();
+        const float mu = (red[c] + red[64 + c] + red[128 + c] + red[192 + c]) / (float)S;
+        __syncthreads();
+        float m2 = 0.f;
+        for (int s0 = w4; s0 < S; s0 += 32) {
+            float v[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+                q[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128 + 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = v[u] - mu;
+                m2 += (s0 + 4 * u < S) ? q[u] + (float)count * d * d : 0.f;
+            }
+        }
+        red[w4 * 64 + c] = m2;
+        __syncthreads();
+        if (w4 == 0) {
+            const float tot = red[c] + red[64 + c] + red[128 + c] + red[192 + c];
+            stat[c] = mu;
+            stat[64 + c] = 1.0f / sqrtf(tot / ((float)S * (float)count) + 1e-5f);
+        }
+        __syncthreads();
+    }
+    const float* mean_b = part ? stat : mean + (size_t)b * 64;
+    const float* rstd_b = part ? stat + 64 : rstd + (size_t)b * 64;
     for (int co = 0; co < Cout; ++co) {
         // B fragments: lane (tap, g) holds w[co][tap][16s + 4g + r] * rstd[16s + 4g + r]
         float4 bf[4];
@@ -549,8 +595,8 @@ __global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict
         for (int s = 0; s < 4; ++s) {
             const int c = 16 * s + 4 * g;
             const float4 wv = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + min(lq, 8)) * 64 + c);
-            const float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)b * 64 + c);
-            const float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)b * 64 + c);
+            const float4 rs = *reinterpret_cast<const float4*>(rstd_b + c);
+            const float4 mu = *reinterpret_cast<const float4*>(mean_b + c);
             const float keep = lq < 9 ? 1.f : 0.f;
             bf[s] = make_float4(wv.x * rs.x * keep, wv.y * rs.y * keep, wv.z * rs.z * keep, wv.w * rs.w * keep);
             wc += (bf[s].x * mu.x + bf[s].y * mu.y) + (bf[s].z * mu.z + bf[s].w * mu.w);
@@ -604,20 +650,29 @@ __global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict
     }
 }
 
+bool final_conv_merges_slices(int H, int W, int Cin) {
+    if (Cin != 64 || W % 16) return false;
+    int R = 8;
+    while (R > 1 && ((R + 2) * W > 1770 || H % R)) R /= 2;
+    return (R + 2) * W <= 1770 && H % R == 0 && 9 * ((R + 2) * W + 1) >= 256;
+}
+
 hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
-                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+                             float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream, const float* part,
+                             int S, int count) {
+    if (part && !final_conv_merges_slices(H, W, Cin)) return hipErrorInvalidValue;
     if (Cin == 64 && W % 16 == 0) {
         int R = 8;  // measured at 64x64: 4 -> 21.6 us, 8 -> 20.7 us, 16 -> 32.3 us
         while (R > 1 && ((R + 2) * W > 1770 || H % R)) R /= 2;
         if ((R + 2) * W <= 1770 && H % R == 0) {
-            const size_t lds2 = (9 * ((size_t)(R + 2) * W + 1) + 16) * sizeof(float);
+            const size_t lds2 = (9 * ((size_t)(R + 2) * W + 1) + 16 + 128) * sizeof(float);
             if (lds2 > 48 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_conv_mfma),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 if (e != hipSuccess) return e;
             }
             hipLaunchKernelGGL(k_final_conv_mfma, dim3(H / R, B), dim3(256), lds2, stream, x, mean, rstd, w, bias, out, H, W,
-                               Cout, R);
+                               Cout, R, part, S, count);
             return hipGetLastError();
         }
     }
