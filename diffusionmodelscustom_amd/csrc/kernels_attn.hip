@@ -31,13 +31,34 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 
 // ABL: timing ablations for tune_flash (results are wrong unless 0): 1 = no exp2, 2 = no V reads from LDS,
 // 4 = no staging/barrier after the first tile, 8 = no QK^T MFMAs, 16 = no PV MFMAs.
-template <int QT, int ABL = 0>
+//
+// PVH: O^T += V^T P^T on the fp16 matrix cores with both operands split in two fp16 halves:
+// V^T P^T ~ Vhi Phi + Vhi Plo + Vlo Phi, three v_mfma_f32_16x16x32_f16 (one per 32 keys, fp32 accumulation)
+// instead of eight fp32 products; the dropped Vlo Plo term is 2^-22 of the product.
+//   P = hi + lo with hi = fp16(P), lo = fp16(P - hi).  P lies in [0, 2^15] (the reference moves at 2^15 in this
+//      form) against a row sum >= 1: a probability above 2^-3 keeps 22 significant bits, a smaller one is off by at
+//      most 2^-25 (lo is then an fp16 subnormal; the matrix cores and the conversions honour subnormals).
+//   V = hi + 2^-11 lo with lo = fp16(2^11 (V - hi)); the Vlo Phi products have an accumulator of their own that is
+//      scaled once, at the end.  |V| in 2^-14 ... 2^15 keeps 22 bits, smaller values are off by at most 2^-36.
+// V tiles are taken this way only while every |V| staged so far is below 2^15 and every 16 keys x 16 columns
+// staged by one wave hold a value of at least 2^-10 (so that the absolute bound is small against the largest
+// value): the staging threads raise a workgroup flag otherwise (also for NaN/Inf), and from that tile on the
+// workgroup multiplies in fp32 as before.
+// (Tried and dropped: a reference 2^11 lower, which would keep Plo out of the subnormals as well.  That kernel gave
+// run-to-run varying results in the second query tile of a wave on strongly peaked rows; the cause was not found.)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int QT, int ABL = 0, bool PVH = true>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
                                                     float scale_log2e) {
     __shared__ __attribute__((aligned(16))) float Ks[2][KVT * KROW];
     __shared__ __attribute__((aligned(16))) float Vs[2][KVT * KROW];
+    // fp16 halves of the V tile in the A-operand order of the 32-deep product: [buffer][hi, lo][32-key half]
+    // [d][g][slot], slot 4j + r <-> key 16j + 4g + r of the half (the order in which a lane holds its 8 scores)
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
+    __shared__ int vbig_s;
+    constexpr float RESCALE = PVH ? 15.f : RESCALE_LOG2;  // log2 of the largest probability relative to the reference
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group).  The linear id is
     // decoded as (bh / 8, query block, bh % 8), so every query block of one (image, head) pair runs on the
@@ -81,11 +102,12 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     // tile (no per-tile accumulator initialisation); lrun[t] keeps the row sum as two partial sums so that the
     // probabilities are added two at a time (packed fp32 adds).
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x4 ot[QT], negm[QT];
+    f32x4 ot[QT], ot2[QT], negm[QT];  // ot2: 2^11 x the Vlo Phi terms of the fp16-halves products
     f32x2 lrun[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         ot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ot2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         negm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         lrun[t] = f32x2{0.f, 0.f};
     }
@@ -94,13 +116,38 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int srow = tid >> 2, sc4 = (tid & 3) * 4;
     float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
     float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * 16 + sc4);
-    *reinterpret_cast<float4*>(&Ks[0][srow * KROW + sc4]) = kreg;
-    *reinterpret_cast<float4*>(&Vs[0][srow * KROW + sc4]) = vreg;
+    // this thread's key within its 32-key half: slot 4j + r of k-group g (see Vh)
+    const int vh_half = srow >> 5, vh_off = ((srow >> 2) & 3) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
+    auto stage = [&](int buf) {
+        *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
+        *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
+        if (PVH) {
+            const float vv[4] = {vreg.x, vreg.y, vreg.z, vreg.w};
+            bool bounded = true, tiny = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const _Float16 hi = (_Float16)vv[c];
+                const _Float16 lo = (_Float16)((vv[c] - (float)hi) * 2048.f);
+                Vh[buf][0][vh_half][(sc4 + c) * 32 + vh_off] = hi;
+                Vh[buf][1][vh_half][(sc4 + c) * 32 + vh_off] = lo;
+                bounded = bounded && (fabsf(vv[c]) < 32768.f);
+                tiny = tiny && (fabsf(vv[c]) < 0.0009765625f);
+            }
+            // never cleared: the tiles from this one on are multiplied in fp32
+            if (!bounded || __all(tiny)) vbig_s = 1;
+        }
+    };
+    if (PVH) {
+        if (tid == 0) vbig_s = 0;
+        __syncthreads();
+    }
+    stage(0);
     __syncthreads();
 
     const int ntiles = L / KVT;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = (ABL & 4) ? 0 : (kt & 1);
+        const bool vbig = PVH ? (__builtin_amdgcn_readfirstlane(vbig_s) != 0) : true;
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
             kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
@@ -139,7 +186,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 const float m1 = max3f(s[t][0][3], s[t][1][0], s[t][1][1]);
                 const float m2 = max3f(s[t][1][2], s[t][1][3], m0);
                 mx[t] = fmaxf(m1, m2);  // lane-local maximum of (score - reference)
-                move = move || (mx[t] > RESCALE_LOG2);
+                move = move || (mx[t] > RESCALE);
             }
             if (__any(move)) {  // wave-uniform; first step, then only if a score runs away from the reference
 #pragma unroll
@@ -147,13 +194,17 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     float m = mx[t];
                     m = fmaxf(m, __shfl_xor(m, 16));
                     m = fmaxf(m, __shfl_xor(m, 32));  // the four lanes that share a query agree on the shift
-                    const float delta = first ? m : ((m > RESCALE_LOG2) ? m : 0.f);
+                    const float delta = first ? m : ((m > RESCALE) ? m : 0.f);
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) negm[t][r] -= delta;
                     lrun[t] *= alpha;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ot[t][r] *= alpha;
+                    if (PVH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ot2[t][r] *= alpha;
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -173,9 +224,32 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     lrun[t] += f32x2{p2, p3};
                 }
             }
-            // ---- O^T += V^T P^T : A = V^T (lane (d, g) holds V[key 4g + r][d]), B = P (the S^T registers)
+            // ---- O^T += V^T P^T : A = V^T, B = P (the S^T registers)
+            if (PVH && !vbig) {  // fp16 halves, 32 keys per product: lane (d, g) holds V[key 16j + 4g + r][d] in slot 4j + r
+                const f16x8 vhi = *reinterpret_cast<const f16x8*>(&Vh[buf][0][hf][(lq * 4 + g) * 8]);
+                const f16x8 vlo = *reinterpret_cast<const f16x8*>(&Vh[buf][1][hf][(lq * 4 + g) * 8]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int t = 0; t < QT; ++t) {
+                    f16x8 phi, plo;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const _Float16 hi = (_Float16)s[t][j][r];
+                            phi[4 * j + r] = hi;
+                            plo[4 * j + r] = (_Float16)(s[t][j][r] - (float)hi);
+                        }
+                    if (!(ABL & 16)) {
+                        ot2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo, phi, ot2[t], 0, 0, 0);
+                        ot[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, plo, ot[t], 0, 0, 0);
+                        ot[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, phi, ot[t], 0, 0, 0);
+                    } else {
+                        ot[t][0] += (float)(vlo[0] * phi[1] + vhi[2] * plo[3] + phi[4] + plo[5] + phi[6] * plo[7]);
+                    }
+                }
+            } else
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {  // fp32: lane (d, g) holds V[key 4g + r][d] for step r
                 float vf[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -190,8 +264,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             }
         }
         if (!(ABL & 4)) {
-            *reinterpret_cast<float4*>(&Ks[buf ^ 1][srow * KROW + sc4]) = kreg;
-            *reinterpret_cast<float4*>(&Vs[buf ^ 1][srow * KROW + sc4]) = vreg;
+            stage(buf ^ 1);
             __syncthreads();
         }
     }
@@ -205,6 +278,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
+        if (PVH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[t][r] += ot2[t][r] * 0.00048828125f;
+        }
         float4 o = make_float4(ot[t][0] * inv, ot[t][1] * inv, ot[t][2] * inv, ot[t][3] * inv);
         *reinterpret_cast<float4*>(O + ((size_t)b * L + q0 + t * 16 + lq) * C + head * 16 + 4 * g) = o;
         // the row's log-sum-exp in the exp2 domain (reference + log2 of the sum), kept for the backward kernels

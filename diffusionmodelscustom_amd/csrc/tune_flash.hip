@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -10,7 +11,10 @@
 
 using namespace danra;
 
-template <int ABL>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
+
+template <int ABL, bool PVH = true>
 static void run(const char* name, const float* q, const float* k, const float* v, float* o, int B, int L) {
     const int heads = 4;
     const float sc = 0.25f * 1.4426950408889634f;
@@ -18,10 +22,10 @@ static void run(const char* name, const float* q, const float* k, const float* v
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL, PVH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e0, 0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL, PVH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -33,16 +37,46 @@ static void run(const char* name, const float* q, const float* k, const float* v
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64, L = argc > 2 ? atoi(argv[2]) : 1024;
+    const float data_scale = argc > 3 ? (float)atof(argv[3]) : 1.f;  // > 1: strongly peaked rows, frequent reference moves
     const size_t n = (size_t)B * L * 64;
     float *q, *k, *v, *o;
     hipMalloc(&q, n * 4); hipMalloc(&k, n * 4); hipMalloc(&v, n * 4); hipMalloc(&o, n * 4);
     std::vector<float> h(n);
     srand(2);
-    for (auto& x : h) x = (float)(rand() % 2001 - 1000) / 500.f;
+    for (auto& x : h) x = data_scale * (float)(rand() % 2001 - 1000) / 500.f;
     hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
     run<0>("full", q, k, v, o, B, L);
+    {   // the fp16-halves product against the all-fp32 product on the same data
+        float* o2;
+        hipMalloc(&o2, n * 4);
+        run<0>("full again", q, k, v, o2, B, L);
+        {
+            std::vector<float> a(n), b(n);
+            hipMemcpy(a.data(), o, n * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(b.data(), o2, n * 4, hipMemcpyDeviceToHost);
+            size_t diff = 0;
+            for (size_t i = 0; i < n; ++i) diff += (a[i] != b[i]);
+            printf("two runs of the same kernel differ in %zu values\n", diff);
+        }
+        run<0, false>("full, PV in fp32", q, k, v, o2, B, L);
+        std::vector<float> a(n), b(n);
+        hipMemcpy(a.data(), o, n * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), o2, n * 4, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0;
+        size_t bad = 0, where = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const double d = fabs((double)a[i] - b[i]);
+            if (!(d <= md)) { md = d; where = i; }
+            if (d > 1e-4) ++bad;
+            if (fabs(b[i]) > mx) mx = fabs(b[i]);
+        }
+        printf("largest difference at image %zu token %zu channel %zu: %.6f against %.6f; %zu of %zu differ by more than 1e-4\n",
+               where / ((size_t)L * 64), (where / 64) % L, where % 64, a[where], b[where], bad, n);
+        printf("max |fp16-halves - fp32| = %.3e  (max |out| %.3e, ratio %.2e)\n", md, mx, md / mx);
+        hipFree(o2);
+    }
     run<1>("no exp2", q, k, v, o, B, L);
     run<2>("no V LDS reads", q, k, v, o, B, L);
     run<4>("no staging/barrier", q, k, v, o, B, L);

@@ -73,6 +73,51 @@ def test_core_forward_and_backward_match_float64(B, heads, L, qscale):
     close(lse2.reshape(B, heads, L), want_lse2, 1e-6, "lse2")
 
 
+@pytest.mark.parametrize("case", ["huge_values_late", "huge_values_first_tile", "tiny_values", "wide_probability_range",
+                                  "nonfinite_value"])
+def test_core_forward_value_ranges(case):
+    """The forward kernel multiplies P V on the fp16 matrix cores (operands split in fp16 halves) while every |V| it has
+    staged is below 2^15, and in fp32 from the first tile on that holds a larger (or non-finite) value.  Both forms, and
+    the switch between them in the middle of a row, stay within the core's tolerance of float64."""
+    B, heads, L = 2, 4, 1024
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn(B, heads, L, 16, generator=g)
+    k = torch.randn(B, heads, L, 16, generator=g)
+    v = torch.randn(B, heads, L, 16, generator=g)
+    if case == "huge_values_late":
+        v[:, 1::2, 640:] *= 3e5          # every second head switches to fp32 products at key 640
+    elif case == "huge_values_first_tile":
+        v[:, :, 3, 5] = -7e6
+    elif case == "tiny_values":
+        v *= 1e-6                        # fp16 subnormals in both halves
+    elif case == "wide_probability_range":
+        q *= 6.0                         # probabilities from 1 down to far below the fp16 range
+        v[:, :, ::7] *= 1e-3
+    elif case == "nonfinite_value":
+        v[0, 0, 700, 3] = float("inf")
+    dout = torch.zeros(B, L, heads * 16)
+    out, _, _, _, lse2 = run_core(q, k, v, dout)
+    p = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 4.0, dim=-1)
+    if case == "nonfinite_value":
+        # as in fp32 arithmetic: the column of head 0, image 0 that meets the infinite value is inf (or nan where its
+        # probability underflows to 0), everything else is untouched
+        col = out[0, :, 3]
+        assert not torch.isfinite(col).any()
+        v[0, 0, 700, 3] = 0.0
+        want = (p @ v.double()).permute(0, 2, 1, 3).reshape(B, L, -1)
+        mask = torch.ones_like(out, dtype=torch.bool)
+        mask[0, :, 3] = False
+        close(out[mask], want[mask], 1e-5, "out beside the non-finite column")
+        return
+    want = (p @ v.double()).permute(0, 2, 1, 3).reshape(B, L, -1)
+    if case.startswith("huge"):
+        # per head: the heads without huge values must not be judged against the huge heads' maximum
+        for h in range(heads):
+            close(out[:, :, 16 * h:16 * h + 16], want[:, :, 16 * h:16 * h + 16], 1e-5, f"out, head {h}")
+    else:
+        close(out, want, 1e-5, "out")
+
+
 def test_core_is_deterministic_and_rejects_other_shapes():
     g = torch.Generator().manual_seed(7)
     q, k, v = (torch.randn(2, 4, 256, 16, generator=g) for _ in range(3))
