@@ -47,7 +47,17 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 // (Tried and dropped: a reference 2^11 lower, which would keep Plo out of the subnormals as well.  That kernel gave
 // run-to-run varying results in the second query tile of a wave on strongly peaked rows; the cause was not found.)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int QT, int ABL = 0, bool PVH = true>
+//
+// QKH: S^T = K Q^T on the fp16 matrix cores as well.  Both operands are split as x = h + 2^-11 l, h = fp16(x),
+// l = fp16(2^11 (x - h)) (Q after its multiplication by hd^-1/2 log2 e); the three products that matter are two
+// 32-deep instructions per 16 keys and query tile with NO arithmetic in the loop (K is split by the staging threads,
+// Q once per kernel):  [Kh | Kl] [Qh | 2^-11 Qh]^T  +  [2^-11 Kh | 0] [Ql | 0]^T  =  Kh Qh + 2^-11 (Kl Qh + Kh Ql).
+// The 2^-11 copies may be fp16 subnormals (quantum 2^-24), which bounds the absolute score error by
+// 16 * 2^-26 (max|K| + max|Q'|) on top of 2^-22 sum|k q'| for the dropped Kl Ql term.  The softmax reference still
+// enters as the C operand of the first product.  The range flag covers |K| and |Q'| < 2^15 as it does V.
+static constexpr int KHROW = 72;  // halves per key row of the fp16 K tile: [h 16 | l 16 | 2^-11 h 16 | zero 16] + 8 of padding
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
@@ -57,7 +67,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     // fp16 halves of the V tile in the A-operand order of the 32-deep product: [buffer][hi, lo][32-key half]
     // [d][g][slot], slot 4j + r <-> key 16j + 4g + r of the half (the order in which a lane holds its 8 scores)
     __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[QKH ? 2 : 1][QKH ? KVT * KHROW : 8];
     __shared__ int vbig_s;
+    static_assert(PVH || !QKH, "the fp16 QK^T product shares the range flag of the fp16 PV product");
     constexpr float RESCALE = PVH ? 15.f : RESCALE_LOG2;  // log2 of the largest probability relative to the reference
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group).  The linear id is
@@ -93,6 +105,28 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         qf[t].w *= scale_log2e;
     }
 
+    // fp16 form of the Q fragments: lane (q, g) holds columns 8 (g & 1) ... + 7; k-groups 0, 1 carry [Qh], [Ql],
+    // k-groups 2, 3 carry [2^-11 Qh], [0] (see QKH above)
+    f16x8 qb1[QT], qb2[QT];
+    bool q_bounded = true;
+    if (QKH) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float* qp = Qb + (size_t)(q0 + t * 16 + lq) * 16 + 8 * (g & 1);
+            const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
+            const float qq[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = qq[i] * scale_log2e;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
+                qb1[t][i] = (g < 2) ? hi : (_Float16)((float)hi * 0.00048828125f);
+                qb2[t][i] = (g < 2) ? lo : (_Float16)0.f;
+                q_bounded = q_bounded && (fabsf(x) < 32768.f);
+            }
+        }
+    }
+
     // Online softmax with a lazily updated reference: the reference is subtracted from the scores by feeding
     // its negative to the QK^T products as their C operand, so the common case needs no per-score
     // arithmetic before exp2.  The reference moves only on the first tile (to that tile's row maximum)
@@ -121,6 +155,23 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     auto stage = [&](int buf) {
         *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
         *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
+        if (QKH) {
+            const float kk[4] = {kreg.x, kreg.y, kreg.z, kreg.w};
+            f16x4 h4, l4, s4;
+            bool bounded = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const _Float16 hi = (_Float16)kk[c];
+                h4[c] = hi;
+                l4[c] = (_Float16)((kk[c] - (float)hi) * 2048.f);
+                s4[c] = (_Float16)((float)hi * 0.00048828125f);
+                bounded = bounded && (fabsf(kk[c]) < 32768.f);
+            }
+            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + sc4]) = h4;
+            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + 16 + sc4]) = l4;
+            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + 32 + sc4]) = s4;
+            if (!bounded) vbig_s = 1;
+        }
         if (PVH) {
             const float vv[4] = {vreg.x, vreg.y, vreg.z, vreg.w};
             bool bounded = true, tiny = true;
@@ -139,7 +190,13 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     };
     if (PVH) {
         if (tid == 0) vbig_s = 0;
+        if (QKH) {  // the zero quarter of every key row, both buffers (the staging never touches it)
+            const f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<f16x4*>(&Kh[0][srow * KHROW + 48 + sc4]) = z;
+            *reinterpret_cast<f16x4*>(&Kh[1][srow * KHROW + 48 + sc4]) = z;
+        }
         __syncthreads();
+        if (QKH && !q_bounded) vbig_s = 1;
     }
     stage(0);
     __syncthreads();
@@ -161,6 +218,17 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             f32x4 s[QT][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (QKH && !vbig) {
+                    const _Float16* krow = &Kh[buf][((2 * hf + j) * 16 + lq) * KHROW + 8 * g];
+                    const f16x8 ka1 = *reinterpret_cast<const f16x8*>(krow);
+                    const f16x8 ka2 = *reinterpret_cast<const f16x8*>(krow + 32);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, qb1[t], negm[t], 0, 0, 0);
+                        s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka2, qb2[t], a, 0, 0, 0);
+                    }
+                    continue;
+                }
                 const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {

@@ -74,11 +74,12 @@ def test_core_forward_and_backward_match_float64(B, heads, L, qscale):
 
 
 @pytest.mark.parametrize("case", ["huge_values_late", "huge_values_first_tile", "tiny_values", "wide_probability_range",
-                                  "nonfinite_value"])
+                                  "nonfinite_value", "huge_keys_late", "huge_queries", "tiny_keys_large_queries"])
 def test_core_forward_value_ranges(case):
-    """The forward kernel multiplies P V on the fp16 matrix cores (operands split in fp16 halves) while every |V| it has
-    staged is below 2^15, and in fp32 from the first tile on that holds a larger (or non-finite) value.  Both forms, and
-    the switch between them in the middle of a row, stay within the core's tolerance of float64."""
+    """The forward kernel multiplies K Q^T and P V on the fp16 matrix cores (operands split in fp16 halves) while every
+    |K|, |V| it has staged and every scaled |Q| of the workgroup is below 2^15, and in fp32 from the first tile on that
+    holds a larger (or non-finite) value.  Both forms, and the switch between them in the middle of a row, stay within
+    the core's tolerance of float64."""
     B, heads, L = 2, 4, 1024
     g = torch.Generator().manual_seed(99)
     q = torch.randn(B, heads, L, 16, generator=g)
@@ -95,6 +96,14 @@ def test_core_forward_value_ranges(case):
         v[:, :, ::7] *= 1e-3
     elif case == "nonfinite_value":
         v[0, 0, 700, 3] = float("inf")
+    elif case == "huge_keys_late":
+        k[:, 1::2, 640:] *= 1e5          # these heads switch to fp32 at key 640 ...
+        q[:, 1::2] *= 1e-5               # ... with scores that stay of order one there (a well-conditioned softmax)
+    elif case == "huge_queries":
+        q[:, ::2, 100:200] *= 2e5        # the workgroups holding these queries multiply in fp32 from the start
+    elif case == "tiny_keys_large_queries":
+        k *= 1e-3                        # low halves and the 2^-11 copies of K deep in the fp16 subnormals
+        q *= 300.0
     dout = torch.zeros(B, L, heads * 16)
     out, _, _, _, lse2 = run_core(q, k, v, dout)
     p = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 4.0, dim=-1)
