@@ -1,10 +1,12 @@
 // Self-attention cores on gfx950.
 //
 // k_flash_hd16: head_dim 16 (every 64-channel level: L = 256 / 1024 / 4096 tokens).  Flash-style:
-// no L x L matrix ever leaves the registers.  fp32 matrix cores (v_mfma_f32_16x16x4_f32) compute
-// S^T = K Q^T, so that a lane holds 16 scores of ONE query (q = lane & 15) and the row maximum / sum
-// are lane-local plus two cross-lane exchanges; the same accumulator registers are then the B
-// operand of O^T = V^T P^T without passing through LDS.  Online softmax in the exp2 domain.
+// no L x L matrix ever leaves the registers.  The matrix cores compute S^T = K Q^T, so that a lane holds
+// 16 scores of ONE query (q = lane & 15) and the row maximum / sum are lane-local plus two cross-lane
+// exchanges; the same accumulator registers are then the B operand of O^T = V^T P^T without passing
+// through LDS.  Online softmax in the exp2 domain.  Both products run as split-operand fp16 products with
+// fp32 accumulation (22 significant bits per operand, see PVH / QKH below) and fall back to the fp32
+// instructions (v_mfma_f32_16x16x4_f32) when an operand leaves the fp16 range.
 //
 // k_attn_reg: the deeper levels (L <= 256 tokens, head_dim 32 / 64 / 128): one wave per 16-query tile, all
 // score tiles in registers, exact two-pass softmax, operands read straight from memory.

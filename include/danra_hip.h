@@ -6,7 +6,9 @@
  * entry point below names the reference Python interface it replaces (file:line relative to the
  * reference tree, DDPM_DANRA_conditional/).  All pointers named *_dev are device pointers owned
  * by the caller (PyTorch tensors in the shipped binding); the library borrows them for the call.
- * Everything is fp32 except the integer timestep / class tensors (int64, as torch.long).
+ * Everything is fp32 except the integer timestep / class tensors (int64, as torch.long).  (Storage and accumulation
+ * are fp32 throughout; the two matrix products of the head_dim-16 attention core are evaluated as fp16 products of
+ * operands split in two halves, 22 significant bits each, with an fp32 fallback when a value leaves the fp16 range.)
  * Every function returns 0 on success or a negative DANRA_E* code and never throws;
  * danra_last_error() returns the message of the calling thread's last failure.
  * All kernels are enqueued on the hipStream_t passed as `stream` (void*, 0 = default stream);
