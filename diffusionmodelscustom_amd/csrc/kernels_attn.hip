@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
                                                     float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) float Ks[2][KVT * KROW];
-    __shared__ __attribute__((aligned(16))) float Vs[2][KVT * KROW];
+    // fp32 tiles only in the all-fp32 form; the fp32 fallback of the fp16 forms (rare) reads global memory instead
+    constexpr bool F32_TILES = !(PVH && QKH);
+    __shared__ __attribute__((aligned(16))) float Ks[F32_TILES ? 2 : 1][F32_TILES ? KVT * KROW : 4];
+    __shared__ __attribute__((aligned(16))) float Vs[F32_TILES ? 2 : 1][F32_TILES ? KVT * KROW : 4];
     // fp16 halves of the V tile in the A-operand order of the 32-deep product: [buffer][hi, lo][32-key half]
     // [d][g][slot], slot 4j + r <-> key 16j + 4g + r of the half (the order in which a lane holds its 8 scores)
     __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
@@ -97,14 +99,18 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
 
     // Q fragments: B operand of S^T = K Q^T: lane (q, g) holds Q[q][4g + r] for MFMA step r.
     // Q is pre-multiplied by hd^-1/2 * log2(e): scores come out of the matrix cores in the exp2 domain.
-    float4 qf[QT];
+    auto load_qf = [&](int t) {
+        float4 f = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+        f.x *= scale_log2e;
+        f.y *= scale_log2e;
+        f.z *= scale_log2e;
+        f.w *= scale_log2e;
+        return f;
+    };
+    float4 qf[F32_TILES ? QT : 1];  // kept in registers only in the all-fp32 form
+    if (F32_TILES) {
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
-        qf[t].x *= scale_log2e;
-        qf[t].y *= scale_log2e;
-        qf[t].z *= scale_log2e;
-        qf[t].w *= scale_log2e;
+        for (int t = 0; t < QT; ++t) qf[t] = load_qf(t);
     }
 
     // fp16 form of the Q fragments: lane (q, g) holds columns 8 (g & 1) ... + 7; k-groups 0, 1 carry [Qh], [Ql],
@@ -155,8 +161,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     // this thread's key within its 32-key half: slot 4j + r of k-group g (see Vh)
     const int vh_half = srow >> 5, vh_off = ((srow >> 2) & 3) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
     auto stage = [&](int buf) {
-        *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
-        *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
+        if (F32_TILES) {
+            *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
+            *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
+        }
         if (QKH) {
             const float kk[4] = {kreg.x, kreg.y, kreg.z, kreg.w};
             f16x4 h4, l4, s4;
@@ -231,17 +239,20 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     }
                     continue;
                 }
-                const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g]);
+                const float4 kf = F32_TILES
+                    ? *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g])
+                    : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * KVT + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     f32x4 a = negm[t];
+                    const float4 qt = F32_TILES ? qf[t] : load_qf(t);
                     if (!(ABL & 8)) {
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t].x, negm[t], 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t].y, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t].z, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t].w, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qt.x, negm[t], 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qt.y, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qt.z, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qt.w, a, 0, 0, 0);
                     } else {
-                        a[0] += kf.x * qf[t].x; a[1] += kf.y; a[2] += kf.z; a[3] += kf.w;
+                        a[0] += kf.x * qt.x; a[1] += kf.y; a[2] += kf.z; a[3] += kf.w;
                     }
                     s[t][j] = a;
                 }
@@ -323,7 +334,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 float vf[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    vf[r] = (ABL & 2) ? qf[0].x + (float)r : Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq];
+                    vf[r] = (ABL & 2) ? scale_log2e + (float)r
+                          : F32_TILES ? Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq]
+                                      : Vb[(size_t)(kt * KVT + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll
