@@ -140,6 +140,8 @@ struct danra_handle_s {
     float* tb_table_u = nullptr;  // label-free rows [T][width] for the unconditional evaluations of a guided loop
     size_t tb_u_cap = 0;
     std::vector<int64_t> h_tb_index;
+    // global index of the first image of the next danra_sample call (Philox counters are per global element)
+    uint64_t first_image = 0;
 };
 
 namespace {
@@ -984,6 +986,11 @@ int danra_attention_core_fwd(const float* q, const float* k, const float* v, flo
     return DANRA_OK;
 }
 
+int danra_set_attention_core_mode(int fp32_products) {
+    set_attention_hd16_fp32_products(fp32_products);
+    return DANRA_OK;
+}
+
 int danra_attention_core_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                              const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads, int L,
                              int head_dim, void* stream) {
@@ -1082,7 +1089,8 @@ int danra_sample_guided(danra_handle_t h, float* x, const int64_t* y, const floa
     if (h->cfg.has_lsm) HIP_TRY(hipMemcpyAsync(ws.lsms, lsm, n * 4, hipMemcpyDeviceToDevice, st));
     if (h->cfg.has_topo) HIP_TRY(hipMemcpyAsync(ws.topos, topo, n * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(launch_init_state(ws.state, T - 1, noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed,
-                              noise_mode == DANRA_NOISE_HOST ? noise : nullptr, cfg_scale, noise_scale, st));
+                              noise_mode == DANRA_NOISE_HOST ? noise : nullptr, cfg_scale, noise_scale,
+                              (unsigned long long)h->first_image * ((unsigned long long)H * W / 4), st));
     RC_TRY(upload_freq(h, st));
 
     // the time projections of every (timestep, class) pair, tabulated once: [T][classes][width]; a guided
@@ -1186,6 +1194,13 @@ int danra_sample_guided(danra_handle_t h, float* x, const int64_t* y, const floa
     }
     h->prof_now = true;
     HIP_TRY(hipMemcpyAsync(x, ws.xs, n * 4, hipMemcpyDeviceToDevice, st));
+    return DANRA_OK;
+}
+
+int danra_set_first_image(danra_handle_t h, uint64_t first_image) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    if (first_image >= (1ull << 40)) return fail(DANRA_EINVAL, "first_image must stay below 2^40");
+    h->first_image = first_image;
     return DANRA_OK;
 }
 
@@ -1310,14 +1325,37 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap, const fl
     return run_decoder_block(h, block, fmap, skip, h->ws.tbias, out, B, H, W, st);
 }
 
+// Scratch of the InstanceNorm pair (statistics kernel + apply kernel): mean[B*C], rstd[B*C], then the sliced partial
+// statistics.  The statistics launcher slices an image over S0 = smallest power of two with HW/S0 <= 1024 workgroups
+// (B*S0*2*C floats) and may slice small problems further, which never needs more than 16384 floats.
+static size_t in_norm_scratch_floats(int B, int HW, int C) {
+    size_t S0 = 1;
+    while ((size_t)HW / S0 > 1024 || (size_t)HW % S0) {
+        S0 *= 2;
+        if (S0 > 4096) return 0;  // no equal slices of at most 1024 pixels: the launcher refuses such a map
+    }
+    return (size_t)2 * B * C + 16384 + (S0 > 1 ? (size_t)2 * B * C * S0 : 0);
+}
+
+static hipError_t instance_norm_launches(const float* x, float* out, int B, int HW, int C, float* scratch_dev,
+                                         size_t scratch_floats, hipStream_t st) {
+    float* mean = scratch_dev;
+    float* rstd = scratch_dev + (size_t)B * C;
+    float* part = scratch_dev + (size_t)2 * B * C;
+    hipError_t e = launch_in_stats(x, mean, rstd, part, scratch_floats - (size_t)2 * B * C, B, HW, C, st);
+    if (e == hipSuccess) e = launch_in_apply(x, mean, rstd, nullptr, nullptr, 0, out, B, HW, C, st);
+    return e;
+}
+
 int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* stream) {
     if (C <= 0 || C % 32) return fail(DANRA_EINVAL, "C must be a positive multiple of 32");
     RC_TRY(op_args(x, out, B, HW));
+    const size_t need = in_norm_scratch_floats(B, HW, C);
+    if (!need) return fail(DANRA_EINVAL, "HW=%d cannot be cut into equal slices of at most 1024 pixels", HW);
     float* stats = nullptr;
-    HIP_TRY(hipMalloc((void**)&stats, (size_t)2 * B * C * 4));
+    HIP_TRY(hipMalloc((void**)&stats, need * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_in_stats(x, stats, stats + (size_t)B * C, nullptr, 0, B, HW, C, st);
-    if (e == hipSuccess) e = launch_in_apply(x, stats, stats + (size_t)B * C, nullptr, nullptr, 0, out, B, HW, C, st);
+    hipError_t e = instance_norm_launches(x, out, B, HW, C, stats, need, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(stats);
     HIP_TRY(e);

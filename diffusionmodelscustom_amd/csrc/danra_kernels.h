@@ -75,6 +75,9 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
                                  int heads, int L, hipStream_t stream);
+// on != 0: every later launch_attention_hd16 multiplies with fp32 matrix instructions only (v_mfma_f32_16x16x4_f32)
+// instead of the split-operand fp16 products.  Process-wide; for numerical cross-checks.
+void set_attention_hd16_fp32_products(int on);
 // Gradients of that forward: dout tokens [B][L][heads*16] -> dq, dk, dv [B*heads][L][16]; delta: [B*heads][L] scratch
 // (receives sum_d dout*out per query).  Two kernels, no atomics.
 hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
@@ -94,9 +97,10 @@ struct SampleState {
     const float* noise;        // host-noise mode: [T-2][n] draws in draw order (timestep T-1 first), or null
     float cfg_scale;           // classifier-free guidance weight (used when the update is given two predictions)
     float noise_scale;         // every draw is multiplied by this (1, or 0.005 for the "scaled data" mode)
+    unsigned long long quad_offset;  // Philox counter of this call's first element quad (a batch slice of a larger batch)
 };
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
-                             float cfg_scale, float noise_scale, hipStream_t stream);
+                             float cfg_scale, float noise_scale, unsigned long long quad_offset, hipStream_t stream);
 // x <- c1*(x - c2*eps) + c3*(noise_scale*z) with (c1, c2, c3) = coef[state->t_upd] and z = 0 at timestep 1.
 // With eps_uncond != null, eps is first replaced by lerp(eps_uncond, eps, cfg_scale).
 hipError_t launch_ddpm_update_state(float* x, const float* eps, const float* eps_uncond, const float4* coef,

@@ -866,12 +866,19 @@ static hipError_t launch_attn_small(const float* q, const float* k, const float*
     return hipGetLastError();
 }
 
+static int g_hd16_fp32_products = 0;
+void set_attention_hd16_fp32_products(int on) { g_hd16_fp32_products = on ? 1 : 0; }
+
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
                                  int heads, int L, hipStream_t stream) {
     if (L % 128 != 0) return hipErrorInvalidValue;
     const float scale_log2e = 0.25f * 1.4426950408889634f;
     dim3 grid((L / 128) * B * heads);
-    hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
+    if (g_hd16_fp32_products)
+        hipLaunchKernelGGL((k_flash_hd16<2, 0, false, false>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads,
+                           B * heads, scale_log2e);
+    else
+        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
     return hipGetLastError();
 }
 

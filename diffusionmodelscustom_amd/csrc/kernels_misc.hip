@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
     const float guide = state->cfg_scale, zs = state->noise_scale;
     const bool noisy = t > 1;
     const bool philox = noisy && state->philox;
-    const unsigned long long seed = state->seed;
+    const unsigned long long seed = state->seed, quad0 = state->quad_offset;
     const float* noise = (noisy && !state->philox && state->noise) ? state->noise + (size_t)(state->t_max - t) * (n4 * 4)
                                                                   : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -805,7 +805,8 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (philox) {
             uint32_t r[4];
-            philox4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)t, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            const unsigned long long q = quad0 + i;  // the element quad's index in the whole (possibly sharded) batch
+            philox4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)t, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
             box_muller(r[0], r[1], z.x, z.y);
             box_muller(r[2], r[3], z.z, z.w);
         } else if (noise) {
@@ -888,7 +889,7 @@ hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alp
 }
 
 __global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
-                             float cfg_scale, float noise_scale) {
+                             float cfg_scale, float noise_scale, unsigned long long quad_offset) {
     if (threadIdx.x == 0) {
         s->t_fwd = t_start;
         s->t_upd = t_start;
@@ -898,12 +899,13 @@ __global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned l
         s->noise = noise;
         s->cfg_scale = cfg_scale;
         s->noise_scale = noise_scale;
+        s->quad_offset = quad_offset;
     }
 }
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
-                             float cfg_scale, float noise_scale, hipStream_t stream) {
+                             float cfg_scale, float noise_scale, unsigned long long quad_offset, hipStream_t stream) {
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, stream, s, t_start, philox, seed, noise, cfg_scale,
-                       noise_scale);
+                       noise_scale, quad_offset);
     return hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ class DiffusionUtils:
         self.show_progress = False
         self.noise_seed = None      # None: derive the Philox seed from torch's generator at each sample() call
         self._host_noise = None     # set by sample_with_host_noise()
+        self.first_image = 0        # index of x[0] in the global batch when this process samples one slice of it
 
     def betaSamples(self):
         """Linear schedule, or the reference's half-cosine ramp from beta_min to beta_max
@@ -98,7 +99,8 @@ class DiffusionUtils:
             host_noise = host_noise.to(device=x.device, dtype=torch.float32)
             assert host_noise.shape[0] >= self.n_timesteps - 2, 'need one noise tensor per step with i > 1'
         return engine.sample(x, *model.hip_call_arguments(y, cond_img, lsm_cond, topo_cond),
-                             self.betas, self.alphas, self.alpha_hat, noise=host_noise, seed=self._philox_seed())
+                             self.betas, self.alphas, self.alpha_hat, noise=host_noise, seed=self._philox_seed(),
+                             first_image=self.first_image)
 
     def _sample_generic(self, x, model, y, cond_img, lsm_cond, topo_cond, host_noise):
         steps = reversed(range(1, self.n_timesteps))

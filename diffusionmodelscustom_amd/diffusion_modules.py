@@ -42,6 +42,7 @@ class DiffusionUtils:
         self.noise_seed = None     # None: derive the Philox seed from torch's generator at each sample() call
         self._host_noise = None    # set by sample_with_host_noise()
         self._start_image = None
+        self.first_image = 0       # index of image 0 in the global batch when this process samples one slice of it
 
     def betaSamples(self):
         """Linear schedule, or beta_t = 1 - abar_t / abar_{t-1} with abar = cos^2(((t/T + 0.008) / 1.008) * pi/2),
@@ -115,7 +116,7 @@ class DiffusionUtils:
             model.hip_call_arguments(None, None, None, None)
         return engine.sample(x, *args, self.betas, self.alphas, self.alpha_hat, noise=host_noise,
                              seed=self._philox_seed(), cfg_scale=float(cfg_scale),
-                             noise_scale=NOISE_SHRINK if self.data_scaled else 1.0)
+                             noise_scale=NOISE_SHRINK if self.data_scaled else 1.0, first_image=self.first_image)
 
     def _sample_generic(self, x, model, y, cond_img, lsm_cond, topo_cond, cfg_scale):
         steps = reversed(range(1, self.n_timesteps))

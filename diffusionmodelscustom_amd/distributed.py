@@ -57,19 +57,48 @@ def shard_batch(rank: int, world: int, *tensors):
     return tuple(out)
 
 
+class _slice_of_global_batch:
+    """While this rank samples images [lo, hi) of a global batch: the in-kernel (Philox) draws are those of the global
+    elements (``diffusion.first_image``), and torch's generators - which the generic step loop draws its per-step noise
+    from - are forked and reseeded from (a number every identically seeded rank draws alike) + lo.  Without this, ranks
+    started with one ``torch.manual_seed`` would all add the same noise to their slices."""
+
+    def __init__(self, diffusion, lo):
+        self.diffusion, self.lo = diffusion, lo
+
+    def __enter__(self):
+        base = int(torch.randint(0, 2 ** 62, (1,)).item())  # advances every rank's generator by the same amount
+        self.saved_first = getattr(self.diffusion, "first_image", 0)
+        self.diffusion.first_image = self.lo
+        # only this process's device: forking every visible device would create a context on each of them
+        self.fork = torch.random.fork_rng(devices=[torch.cuda.current_device()] if torch.cuda.is_available() else [])
+        self.fork.__enter__()
+        torch.manual_seed((base + 0x9E3779B97F4A7C15 * (self.lo + 1)) % (2 ** 63))
+        return self
+
+    def __exit__(self, *exc):
+        self.fork.__exit__(*exc)
+        self.diffusion.first_image = self.saved_first
+        return False
+
+
 def sample_sharded(diffusion, model, x, y=None, cond_img=None, lsm_cond=None, topo_cond=None, gather=True,
                    host_noise=None):
     """``diffusion.sample`` on this rank's slice of the global batch.  With ``gather`` every rank returns the
-    whole batch in the original order (ragged slices are padded for the all-gather and trimmed after it)."""
+    whole batch in the original order (ragged slices are padded for the all-gather and trimmed after it).  A rank
+    whose slice is empty (batch smaller than the world) samples nothing and still takes part in the gather."""
     rank, world = _world()
     batch = x.shape[0]
+    lo, hi = shard_range(batch, rank, world)
     xs, ys, cs, ls, ts = shard_batch(rank, world, x, y, cond_img, lsm_cond, topo_cond)
-    if host_noise is not None:
-        lo, hi = shard_range(batch, rank, world)
+    if hi == lo:
+        local = xs.detach().clone()
+    elif host_noise is not None:
         local = diffusion.sample_with_host_noise(xs, model, host_noise[:, lo:hi], ys, cond_img=cs, lsm_cond=ls,
                                                  topo_cond=ts)
     else:
-        local = diffusion.sample(xs, model, ys, cond_img=cs, lsm_cond=ls, topo_cond=ts)
+        with _slice_of_global_batch(diffusion, lo):
+            local = diffusion.sample(xs, model, ys, cond_img=cs, lsm_cond=ls, topo_cond=ts)
     if not gather or world == 1:
         return local
     return _gather_ragged(local, batch, world)
@@ -92,18 +121,25 @@ def sample_sharded_clean(diffusion, model, n, channels_hr, y=None, cond_img=None
                          cfg_scale=0.0, gather=True, host_noise=None, start_image=None):
     """The same sharding for ``diffusion_modules.DiffusionUtils.sample(n, model, channels_hr, ...)`` (the sampler that
     draws its own start image): this rank samples its slice of the ``n`` images with the matching slices of the
-    conditioning tensors.  Start images and noise come from each rank's own generator unless ``start_image`` /
-    ``host_noise`` (global tensors, sliced here) are given."""
+    conditioning tensors.  Without ``start_image`` every rank draws the start images of the WHOLE batch on the host, as
+    the unsharded sampler does, and keeps its slice (identically seeded ranks thus start from different images, and from
+    the same images the unsharded call would use); per-step noise as in ``sample_sharded`` unless ``host_noise`` (a
+    global tensor, sliced here) is given."""
     rank, world = _world()
     lo, hi = shard_range(n, rank, world)
     ys, cs, ls, ts = shard_batch(rank, world, y, cond_img, lsm_cond, topo_cond)
-    if host_noise is not None or start_image is not None:
-        local = diffusion.sample_with_host_noise(
-            hi - lo, model, channels_hr, None if host_noise is None else host_noise[:, lo:hi],
-            start_image=None if start_image is None else start_image[lo:hi], y=ys, cond_img=cs, lsm_cond=ls,
-            topo_cond=ts, cfg_scale=cfg_scale)
+    if start_image is None:
+        start_image = torch.randn((n, channels_hr, diffusion.img_size, diffusion.img_size))
+    if hi == lo:
+        local = start_image[lo:hi].to(diffusion.device)
+    elif host_noise is not None:
+        local = diffusion.sample_with_host_noise(hi - lo, model, channels_hr, host_noise[:, lo:hi],
+                                                 start_image=start_image[lo:hi], y=ys, cond_img=cs, lsm_cond=ls,
+                                                 topo_cond=ts, cfg_scale=cfg_scale)
     else:
-        local = diffusion.sample(hi - lo, model, channels_hr, ys, cs, ls, ts, cfg_scale)
+        with _slice_of_global_batch(diffusion, lo):
+            local = diffusion.sample_with_host_noise(hi - lo, model, channels_hr, None, start_image=start_image[lo:hi],
+                                                     y=ys, cond_img=cs, lsm_cond=ls, topo_cond=ts, cfg_scale=cfg_scale)
     if not gather or world == 1:
         return local
     return _gather_ragged(local, n, world)

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "danra_noise_image": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_set_attention_core_mode": (ctypes.c_int, [ctypes.c_int]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
     "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -69,6 +70,7 @@ _SIGNATURES = {
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
+    "danra_set_first_image": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                          ctypes.POINTER(ctypes.c_double)]),
@@ -179,14 +181,22 @@ def noise_image(x, t, alpha_hat, noise=None, seed=0, offset=0):
     return noisy, z
 
 
+# Under autocast the autograd Functions below receive their tensor inputs cast to float32 and run with autocast off;
+# their backward passes run the same way.
+_custom_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_custom_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
 class _AttentionCoreHD16(torch.autograd.Function):
     """softmax(q k^T / 4) v per head with head_dim 16, forward and backward in libdanra_hip.so
     (danra_attention_core_fwd / _bwd): the L x L score matrices exist only in registers in either direction.
     qkv: [3, B, heads, L, 16] contiguous -> tokens [B, L, heads*16]."""
 
     @staticmethod
+    @_custom_fwd
     def forward(ctx, qkv):
         lib = load_library()
+        qkv = qkv.contiguous()
         _, B, heads, L, hd = qkv.shape
         out = torch.empty((B, L, heads * hd), device=qkv.device, dtype=torch.float32)
         lse2 = torch.empty((B * heads, L), device=qkv.device, dtype=torch.float32)
@@ -197,6 +207,7 @@ class _AttentionCoreHD16(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_custom_bwd
     def backward(ctx, dout):
         lib = load_library()
         qkv, out, lse2 = ctx.saved_tensors
@@ -211,10 +222,19 @@ class _AttentionCoreHD16(torch.autograd.Function):
         return dqkv
 
 
+def _native_dtype(x):
+    """float32 always; under autocast (the reference's training loop runs its forward inside `autocast()`,
+    training_DANRA_conditional.py:962-971) also the half-precision tensors autocast hands over: the native kernels
+    then take them cast to float32 and return float32, which autocast's next operator casts down again as it would
+    any float32 input."""
+    return x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.float16, torch.bfloat16))
+
+
 def attention_core_supported(tokens, n_heads):
     """True when the differentiable self-attention of [B, L, C] `tokens` can run its core in the native library:
-    CUDA fp32 outside autocast, head_dim 16, L a multiple of 128 (the 64-channel levels of the 4-head network)."""
-    return (native_training_kernels and tokens.is_cuda and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
+    a CUDA tensor (float32; half precision under autocast), head_dim 16, L a multiple of 128 (the 64-channel levels
+    of the 4-head network)."""
+    return (native_training_kernels and tokens.is_cuda and _native_dtype(tokens)
             and tokens.shape[-1] == 16 * n_heads and tokens.shape[1] % 128 == 0
             and tokens.shape[0] * n_heads * tokens.shape[1] < (1 << 27))
 
@@ -225,7 +245,7 @@ def differentiable_self_attention(mha, tokens):
     B, L, C = tokens.shape
     heads = mha.num_heads
     qkv = torch.nn.functional.linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
-    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous()
+    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # made contiguous (and float32) by the core
     attended = _AttentionCoreHD16.apply(qkv)
     return torch.nn.functional.linear(attended, mha.out_proj.weight, mha.out_proj.bias)
 
@@ -235,8 +255,10 @@ class _BatchNormTrain(torch.autograd.Function):
     libdanra_hip.so (danra_batchnorm_train_fwd / _bwd).  The running statistics are updated in place by the kernel."""
 
     @staticmethod
+    @_custom_fwd
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
         lib = load_library()
+        x = x.contiguous()
         B, C, H, W = x.shape
         y = torch.empty_like(x)
         save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -251,6 +273,7 @@ class _BatchNormTrain(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_custom_bwd
     def backward(ctx, dy):
         lib = load_library()
         x, y, gamma, save_mean, save_rstd = ctx.saved_tensors
@@ -267,9 +290,11 @@ class _BatchNormTrain(torch.autograd.Function):
 
 def batchnorm_train_supported(bn, x):
     """True when `bn(x)` in train mode can run in the native library: affine BatchNorm2d with running statistics and a
-    fixed momentum, on a contiguous NCHW fp32 CUDA tensor outside autocast whose H*W is a multiple of 4."""
+    fixed momentum, on a 4-D CUDA tensor (float32; half precision under autocast) whose H*W is a multiple of 4.  A
+    tensor that is not contiguous NCHW (a convolution fed by an attention block's output hands over channels-last
+    strides) is copied first."""
     return (native_training_kernels and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled()
+            and _native_dtype(x) and x.dim() == 4 and bn.weight.dtype == torch.float32
             and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 2 and x.numel() < (1 << 31))
 
 
@@ -286,8 +311,10 @@ class _InstanceNorm(torch.autograd.Function):
     (danra_instancenorm_fwd / _bwd)."""
 
     @staticmethod
+    @_custom_fwd
     def forward(ctx, x, eps):
         lib = load_library()
+        x = x.contiguous()
         B, C, H, W = x.shape
         y = torch.empty_like(x)
         save_mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
@@ -299,6 +326,7 @@ class _InstanceNorm(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_custom_bwd
     def backward(ctx, dy):
         lib = load_library()
         x, save_mean, save_rstd = ctx.saved_tensors
@@ -312,10 +340,10 @@ class _InstanceNorm(torch.autograd.Function):
 
 
 def instance_norm(module, x):
-    """`module(x)`; an nn.InstanceNorm2d without affine parameters or running statistics on a contiguous NCHW fp32 CUDA
-    tensor (H*W a multiple of 4, outside autocast) runs forward and backward in the native library."""
+    """`module(x)`; an nn.InstanceNorm2d without affine parameters or running statistics on a 4-D CUDA tensor (float32;
+    half precision under autocast; H*W a multiple of 4) runs forward and backward in the native library."""
     if (native_training_kernels and type(module) is torch.nn.InstanceNorm2d and not module.affine and not module.track_running_stats and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled()
+            and _native_dtype(x) and x.dim() == 4
             and (x.shape[2] * x.shape[3]) % 4 == 0 and x.numel() < (1 << 31)):
         return _InstanceNorm.apply(x, float(module.eps))
     return module(x)
@@ -420,10 +448,11 @@ class UNetEngine:
         return tuple(outs)
 
     def sample(self, x, y, cond_img, lsm_cond, topo_cond, betas, alphas, alpha_hat, noise=None, seed=0,
-               trace_steps=None, cfg_scale=0.0, noise_scale=1.0):
+               trace_steps=None, cfg_scale=0.0, noise_scale=1.0, first_image=0):
         """Whole reverse loop on the device.  x is updated in place and returned.  `noise` (a CUDA
         tensor [(T-2), B, 1, H, W]) selects host-noise mode, otherwise Philox noise from `seed`.
-        cfg_scale > 0: classifier-free guidance (two evaluations per step); noise_scale multiplies every draw."""
+        cfg_scale > 0: classifier-free guidance (two evaluations per step); noise_scale multiplies every draw.
+        first_image: index of x[0] in the global batch this call samples a slice of (Philox draws are per global element)."""
         x = _f32(x, "x")
         B, _, H, W = x.shape
         _check_labels(y, self.cfg.num_classes)
@@ -442,6 +471,8 @@ class UNetEngine:
             trace = torch.empty((n_trace,) + tuple(x.shape), device=x.device, dtype=torch.float32)
         yy = _i64(y, "y")
         cc, ll, tt = _f32(cond_img, "cond_img"), _f32(lsm_cond, "lsm_cond"), _f32(topo_cond, "topo_cond")
+        _check(self.lib, self.lib.danra_set_first_image(self.handle, ctypes.c_uint64(int(first_image))),
+               "danra_set_first_image")
         with torch.cuda.device(x.device):
             _check(self.lib, self.lib.danra_sample_guided(
                 self.handle, _ptr(x), _ptr(yy), _ptr(cc), _ptr(ll), _ptr(tt), B, H, W, T, _ptr(hb), _ptr(ha), _ptr(hh),

@@ -47,8 +47,9 @@ class GraphedTrainStep:
       torch's graph-safe generator), or - ``external_draws=True`` - taken from the ``t=`` / ``noise=`` arguments of
       every call.
     * Warm-up (required before capture, so that every lazy initialisation and solver search has happened) runs
-      ``warmup`` real steps on the example batch and then puts parameters, buffers and optimizer state back, so that
-      constructing the object does not train the model.
+      ``warmup`` real steps on the example batch and then puts parameters, buffers, the optimizer's state (moments and
+      step counters restored by ``load_state_dict`` included) and the random generators' states back, so that
+      constructing the object does not train the model.  SGD with momentum AND dampening must have taken a step before.
     * The returned loss is a device tensor that the next call overwrites; ``.item()`` it (one host sync, as in the
       reference's loop) or accumulate it on the device.
     """
@@ -73,6 +74,18 @@ class GraphedTrainStep:
             self.static.setdefault("noise", torch.zeros_like(images))
 
         saved_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        # what the optimizer knew before the warm-up (e.g. moments restored by load_state_dict), per parameter
+        saved_opt = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                     for p, st in optimizer.state.items()}
+        if not saved_opt:
+            for group in optimizer.param_groups:
+                if group.get("momentum", 0) and group.get("dampening", 0):
+                    # SGD's first step copies the gradient into a momentum buffer it creates; a buffer that exists and
+                    # holds zeros gets (1 - dampening) * gradient instead, so the warm-up cannot be undone by zero-filling
+                    raise RuntimeError("SGD with momentum and dampening != 0 must have taken one step before it is "
+                                       "captured (its first step differs from the later ones)")
+        cpu_rng = torch.get_rng_state()
+        dev_rng = torch.cuda.get_rng_state(images.device)
         side = torch.cuda.Stream(device=images.device)
         side.wait_stream(torch.cuda.current_stream(images.device))
         with torch.cuda.stream(side):
@@ -80,20 +93,30 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream(images.device).wait_stream(side)
         torch.cuda.synchronize(images.device)
-        # undo the warm-up: parameters and buffers in place (the graph will refer to these very tensors), optimizer
-        # moments and step counters to zero
+        # undo the warm-up, in place (the graph will refer to these very tensors): parameters and buffers, the optimizer
+        # state (what it held before; moments and step counters the warm-up created go back to zero, which is where a
+        # fresh optimizer starts); the generators' states follow after the capture
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(saved_model[k])
-            for state in optimizer.state.values():
-                for v in state.values():
-                    if torch.is_tensor(v):
+            for p, state in optimizer.state.items():
+                before = saved_opt.get(p)
+                for k, v in list(state.items()):
+                    if before is not None and k in before:
+                        if torch.is_tensor(v):
+                            v.copy_(before[k])
+                        else:
+                            state[k] = before[k]
+                    elif torch.is_tensor(v):
                         v.zero_()
         model.zero_grad(set_to_none=True)
 
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
+        # warm-up and capture drew from the generators (the capture only records its draws, it does not make them)
+        torch.set_rng_state(cpu_rng)
+        torch.cuda.set_rng_state(dev_rng, images.device)
 
     def _body(self):
         s = self.static

@@ -159,6 +159,11 @@ int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alp
  * log-sum-exp of every query's scaled scores in the exp2 domain. */
 int danra_attention_core_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, float* lse2_dev,
                              int B, int heads, int L, int head_dim, void* stream);
+/* Numerics switch of the head_dim-16 attention core (no counterpart in the reference; process-wide, affects
+ * danra_attention_core_fwd and the sampling path alike): fp32_products != 0 makes every later launch multiply with fp32
+ * matrix instructions only (slower), 0 restores the default split-operand fp16 products.  Both forms meet the same
+ * tolerance against float64; the switch exists so that a caller can cross-check one against the other. */
+int danra_set_attention_core_mode(int fp32_products);
 /* Gradients of danra_attention_core_fwd: dout_dev = dLoss/dout (layout of out) -> dq, dk, dv (layout of q, k, v).
  * out_dev and lse2_dev are the forward's results; delta_dev: [B*heads][L] scratch.  Two kernels (one accumulates dq
  * over the keys, one dk and dv over the queries), no atomics: results are deterministic. */
@@ -188,6 +193,13 @@ int danra_instancenorm_fwd(const float* x_dev, float* y_dev, float* save_mean_de
                            float eps, void* stream);
 int danra_instancenorm_bwd(const float* x_dev, const float* dy_dev, const float* save_mean_dev, const float* save_rstd_dev,
                            float* dx_dev, int planes, int HW, void* stream);
+
+/* Batch sharding of the in-kernel noise (no counterpart in the reference, which samples on one device): the calls
+ * to danra_sample / danra_sample_guided that follow treat their image 0 as image `first_image` of a larger batch:
+ * with DANRA_NOISE_PHILOX the draw for element e of local image b at a timestep is that of global element
+ * (first_image + b) * H*W + e, so the slices of one batch sampled by several processes with one seed draw
+ * different noise, and the same noise as the unsliced batch would on one device.  Default 0.  Sticky per handle. */
+int danra_set_first_image(danra_handle_t h, uint64_t first_image);
 
 /* Sampling-loop execution mode (no counterpart in the reference): enable != 0 replays a captured
  * hipGraph per denoise step (default; the environment variable DANRA_GRAPH=0 at danra_create time turns

@@ -71,6 +71,96 @@ def _worker(rank, world, port, batch, out_dir):
     dist.destroy_process_group()
 
 
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker_same_seed(rank, world, port, out_dir):
+    """Every rank calls torch.manual_seed(123), as a torchrun script usually does, and all images share one start image
+    and one conditioning: the per-step noise is then the only thing that can tell two images apart."""
+    _init(rank, world, port)
+    from diffusionmodelscustom_amd import DiffusionUtils
+    from diffusionmodelscustom_amd import diffusion_modules as dm
+    from diffusionmodelscustom_amd.distributed import sample_sharded, sample_sharded_clean
+    from diffusionmodelscustom_amd.synthetic import synthetic_inputs
+    from model_util import build_clean_model, build_model
+
+    torch.manual_seed(123)
+    batch, T = 4, 4
+    one = synthetic_inputs(1, 32, 32, seed=3)
+    rep = {k: v.expand(batch, *v.shape[1:]).contiguous() for k, v in one.items()}
+    model = build_model("cond", 32)
+    du = DiffusionUtils(T, 1e-4, 0.02, "cpu", "linear")
+    out = sample_sharded(du, model, rep["x"], rep["y"], rep["cond_img"], rep["lsm_cond"], rep["topo_cond"])
+    assert du.first_image == 0, "the slice offset must not outlive the call"
+    for a in range(batch):
+        for b in range(a + 1, batch):
+            assert float((out[a] - out[b]).abs().max()) > 1e-3, f"images {a} and {b} were given the same noise"
+    torch.save(out, os.path.join(out_dir, f"same_seed_rank{rank}.pt"))
+
+    # the sampler that draws its own start images: identically seeded ranks must not start from the same images either
+    cmodel = build_clean_model("clean_class", 32)
+    cdu = dm.DiffusionUtils(T, 1e-4, 0.02, "cpu", "linear", img_size=32)
+    y = torch.zeros(batch, dtype=torch.long)
+    outc = sample_sharded_clean(cdu, cmodel, batch, 1, y=y)
+    for a in range(batch):
+        for b in range(a + 1, batch):
+            assert float((outc[a] - outc[b]).abs().max()) > 1e-3, f"clean sampler: images {a} and {b} coincide"
+
+    # fewer images than ranks: the rank with the empty slice still takes part in the gather
+    small = sample_sharded(du, model, rep["x"][:1], rep["y"][:1], rep["cond_img"][:1], rep["lsm_cond"][:1],
+                           rep["topo_cond"][:1])
+    assert small.shape == (1, 1, 32, 32) and torch.isfinite(small).all()
+    smallc = sample_sharded_clean(cdu, cmodel, 1, 1, y=y[:1])
+    assert smallc.shape == (1, 1, 32, 32)
+    torch.save(small, os.path.join(out_dir, f"small_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_identically_seeded_ranks_draw_different_noise(tmp_path):
+    mp.spawn(_worker_same_seed, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "same_seed_rank0.pt"), torch.load(tmp_path / "same_seed_rank1.pt")
+    assert torch.equal(a, b)
+    assert torch.equal(torch.load(tmp_path / "small_rank0.pt"), torch.load(tmp_path / "small_rank1.pt"))
+
+
+def _worker_c4_split(rank, world, port, out_dir):
+    """The 128x128 benchmark configuration's split (global batch 256 -> 128 per rank at world size 2; a node of eight
+    gives 32 each) at a 32x32 stand-in size: slices are contiguous, the gathered batch keeps the global order."""
+    _init(rank, world, port)
+    from diffusionmodelscustom_amd import DiffusionUtils
+    from diffusionmodelscustom_amd.distributed import sample_sharded, shard_range
+    from diffusionmodelscustom_amd.synthetic import synthetic_inputs
+    from model_util import build_model
+
+    batch, T = 256, 2  # T = 2: one evaluation, the update adds no noise, so single images can be re-evaluated exactly
+    inp = synthetic_inputs(batch, 32, 32, seed=5)
+    model = build_model("cond", 32)
+    du = DiffusionUtils(T, 1e-4, 0.02, "cpu", "linear")
+    assert shard_range(batch, rank, world) == (128 * rank, 128 * rank + 128)
+    out = sample_sharded(du, model, inp["x"], inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+    assert out.shape == (batch, 1, 32, 32)
+    if rank == 0:
+        pick = torch.tensor([0, 127, 128, 255])
+        want = du.sample(inp["x"][pick], model, inp["y"][pick], cond_img=inp["cond_img"][pick],
+                         lsm_cond=inp["lsm_cond"][pick], topo_cond=inp["topo_cond"][pick])
+        assert float((out[pick] - want).abs().max() / want.abs().max()) < 1e-5
+    torch.save(out, os.path.join(out_dir, f"c4_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_split_keeps_global_order(tmp_path):
+    mp.spawn(_worker_c4_split, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert torch.equal(torch.load(tmp_path / "c4_rank0.pt"), torch.load(tmp_path / "c4_rank1.pt"))
+
+
 @pytest.mark.parametrize("batch", [4, 3])  # even and ragged split over two ranks
 def test_sharded_sampling_world2(tmp_path, batch):
     port = _free_port()

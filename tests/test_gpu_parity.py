@@ -349,6 +349,33 @@ def test_sampler_loop_equals_its_parts(cond64, dev):
     assert torch.equal(got, x)
 
 
+def test_slices_of_a_batch_draw_the_noise_of_the_whole_batch(cond64, dev):
+    """Two processes that sample the halves of one batch with one seed (batch sharding over GPUs) must not add the same
+    noise to both halves: with first_image the in-kernel draws are those of the global elements, so the two slices
+    together equal the unsliced call (an image does not depend on its batch neighbours beyond rounding) and identical
+    inputs at different global positions give different samples."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, _ = cond64
+    engine = model.hip_engine(dev)
+    T, B, seed = 6, 4, 77
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    one = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 1, 64, seed=8).items()}
+    inp = {k: v.expand(B, *v.shape[1:]).contiguous() for k, v in one.items()}
+
+    def run(lo, hi, first):
+        return engine.sample(inp["x"][lo:hi].clone(), inp["y"][lo:hi], inp["cond_img"][lo:hi], inp["lsm_cond"][lo:hi],
+                             inp["topo_cond"][lo:hi], du.betas, du.alphas, du.alpha_hat, seed=seed, first_image=first)
+    whole = run(0, B, 0)
+    halves = torch.cat([run(0, 2, 0), run(2, 4, 2)])
+    assert rel_err(halves.cpu(), whole.cpu()) < TOL_CHAIN
+    for a in range(B):
+        for b in range(a + 1, B):
+            assert float((whole[a] - whole[b]).abs().max()) > 1e-2, (a, b)
+    same_stream = run(2, 4, 0)  # without the offset the second half repeats the first half's noise
+    assert rel_err(same_stream.cpu(), whole[:2].cpu()) < TOL_CHAIN
+    assert torch.equal(run(0, 2, 0), run(0, 2, 0))  # the offset is per call: a later plain call is unchanged
+
+
 def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
     """B = 33 at 64x64 puts 33792 tokens through the K=64 row-stationary GEMM (QKV at L=1024, final transposed
     convolution) with a partly empty last workgroup; every image must equal its own B = 1 evaluation."""
