@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -820,6 +821,8 @@ int check_ready(danra_handle_s* h, int B, int H, int W) {
 
 }  // namespace
 
+static int resolve_scratch(float** out);
+
 // ================================================================================================
 extern "C" {
 
@@ -851,6 +854,15 @@ int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
         const float e = (float)(2 * k) / (float)cfg->time_embedding;  // arange(0, dim, 2).float() / dim
         h->h_enc_inv_freq[k] = 1.0f / (float)pow(1000.0, (double)e);
         h->h_dec_div[k] = (float)pow(10000.0, (double)(2 * k) / (double)cfg->time_embedding);
+    }
+    // library set-up for this device: the address of the built-in scratch array (danra_instance_norm_noalloc)
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        float* unused = nullptr;
+        const int rc = resolve_scratch(&unused);
+        if (rc != DANRA_OK) { delete h; return rc; }
+    } else {
+        (void)hipGetLastError();  // no device in this process: nothing to resolve
     }
     *out = h;
     return DANRA_OK;
@@ -1359,6 +1371,47 @@ int danra_instance_norm(const float* x, float* out, int B, int HW, int C, void* 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(stats);
     HIP_TRY(e);
+    return DANRA_OK;
+}
+
+// ---- the same operator for callers that cannot allocate: its scratch lives in the code object itself.
+// `scratch` below is the HOST-side handle of a device array: every GPU the library runs on holds its own copy at its
+// own address, which hipGetSymbolAddress resolves once per device; host code uses that address, never the symbol.
+constexpr size_t kNoAllocScratchFloats = (size_t)1 << 20;  // 4 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[kNoAllocScratchFloats];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_dev[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+// The address of `scratch` on the current device (resolved on the first call per device).
+static int resolve_scratch(float** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(DANRA_EINVAL, "device ordinal %d is outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_dev[dev]) {
+        float* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(DANRA_EHIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_dev[dev] = p;
+    }
+    *out = g_scratch_dev[dev];
+    return DANRA_OK;
+}
+
+int danra_instance_norm_noalloc(const float* x, float* out, int B, int HW, int C, void* stream) {
+    if (C <= 0 || C % 32) return fail(DANRA_EINVAL, "C must be a positive multiple of 32");
+    RC_TRY(op_args(x, out, B, HW));
+    const size_t need = in_norm_scratch_floats(B, HW, C);
+    if (!need) return fail(DANRA_EINVAL, "HW=%d cannot be cut into equal slices of at most 1024 pixels", HW);
+    if (need > kNoAllocScratchFloats)
+        return fail(DANRA_EINVAL, "B=%d HW=%d C=%d needs %zu floats of scratch, the built-in array holds %zu: use "
+                    "danra_instance_norm or a smaller batch", B, HW, C, need, (size_t)kNoAllocScratchFloats);
+    float* dev_scratch = nullptr;
+    RC_TRY(resolve_scratch(&dev_scratch));
+    // every word of the scratch that the apply kernel or the merge reads is written by the statistics kernel of this
+    // very call first, so nothing needs clearing between calls
+    HIP_TRY(instance_norm_launches(x, out, B, HW, C, dev_scratch, kNoAllocScratchFloats, (hipStream_t)stream));
     return DANRA_OK;
 }
 

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "danra_resnet_layer": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_decoder_block": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_instance_norm": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_instance_norm_noalloc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_nchw_to_nhwc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_nhwc_to_nchw": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
 }

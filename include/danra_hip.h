@@ -247,6 +247,15 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap_nhwc, con
                         const int64_t* t_dev, float* out_nhwc, int B, int H, int W, void* stream);
 /* InstanceNorm2d(affine=False, eps=1e-5) (modules:412,419) on NHWC. */
 int danra_instance_norm(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
+/* danra_instance_norm for callers that cannot allocate device memory (code under hipGraph capture, serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arithmetic and results as
+ * danra_instance_norm, but the statistics scratch is a 4 MiB array built into the library (one copy per GPU, held until
+ * the process ends) instead of a hipMalloc per call, and the call is asynchronous on `stream` (no host synchronisation).
+ * Refused with DANRA_EINVAL when 2*B*C + 16384 (+ 2*B*C*S for maps above 1024 pixels, S = HW/1024 rounded up to a
+ * power of two) exceeds 2^20 floats.  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams or threads) race; calls on one stream are ordered.  The array's address is resolved once per device, by
+ * danra_create or by the first call on that device (which must therefore not be made under stream capture). */
+int danra_instance_norm_noalloc(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
 /* NCHW <-> NHWC helpers for the tests. */
 int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream);
 int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void* stream);
