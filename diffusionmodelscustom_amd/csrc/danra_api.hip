@@ -49,7 +49,15 @@ struct ParamEntry {
     const float* src = nullptr;
 };
 
+// A packed weight matrix that k_igemm may multiply in its split-operand fp16 form: a second copy in that form
+// (launch_split_weights) and the power-of-two scale it carries.  Null when the matrix is not eligible.
+struct SplitW {
+    float* wh = nullptr;
+    float inv_scale = 1.0f;
+};
+
 struct ConvP {
+    SplitW split;
     float* w = nullptr;     // [Cout][KH][KW][Cin] (stem: [Cout][Cin][KH][KW])
     float* bias = nullptr;  // folded BatchNorm shift or conv bias (may be null)
     int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
@@ -61,6 +69,7 @@ struct AttnP {
     float* b_out = nullptr;
     // feed-forward block of the clean-application network (src/unet.py:91-96): LayerNorm folded into the first Linear
     float *w_ff1 = nullptr, *b_ff1 = nullptr, *w_ff2 = nullptr, *b_ff2 = nullptr;
+    SplitW s_in, s_out, s_ff1, s_ff2;
     int C = 0;
 };
 struct BlockP {
@@ -74,6 +83,7 @@ struct BlockP {
 struct DecP {
     float* wt = nullptr;  // [4*Cin][Cin]
     float* bt = nullptr;  // [4*Cin]
+    SplitW s_wt;
     ConvP conv;
     AttnP attn;
     int Cin = 0, Cout = 0;
@@ -112,6 +122,8 @@ struct danra_handle_s {
     // packed model
     void* arena = nullptr;
     size_t arena_bytes = 0;
+    void* arena_h = nullptr;  // the split-operand copies of the eligible matrices, then one float per matrix (max |w|)
+    size_t arena_h_bytes = 0;
     bool packed = false;
     ConvP stem, conv2, final_conv;
     std::vector<BlockP> blocks[4];
@@ -130,6 +142,8 @@ struct danra_handle_s {
     std::vector<hipEvent_t> prof_events;
     size_t prof_used = 0;
     double prof_flops = 0.0;
+    double prof_exec_flops = 0.0;   // multiply-adds the instructions executed (x2), see igemm()
+    double prof_split_flops = 0.0;  // the part of prof_flops that ran in the split-operand fp16 form
     // sampling loop: 1 = replay one captured denoise step (hipGraph), 0 = enqueue every kernel
     int graph_mode = 1;
     hipStream_t cap_stream = nullptr;
@@ -246,15 +260,31 @@ const float* src_of(danra_handle_s* h, const std::string& name) {
     return it == h->index.end() ? nullptr : h->params[it->second].src;
 }
 
-// Lays out (and on the second pass fills) the packed arena.
-int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
+// A matrix registered for splitting while the arena is laid out; split_registered() fills the copies afterwards.
+struct SplitJob {
+    const float* w;
+    size_t n;
+    SplitW* dst;
+};
+
+// Lays out (and on the second pass fills) the packed arena; `bh` lays out the arena of split-operand copies.
+int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>& jobs, bool fill, hipStream_t st) {
     const int dim = h->cfg.time_embedding;
+    // k_igemm's split-operand form needs rows of whole 64-deep chunks and pays from K = 128 on (the K = 64 products
+    // go through the row-stationary kernels, which are bound by memory, not by the matrix cores)
+    auto want_split = [&](SplitW& s, float* w, size_t rows, size_t K) {
+        s = SplitW();
+        if (K % 64 || K < 128) return;
+        s.wh = bh.take(rows * K);
+        jobs.push_back({w, rows * K, &s});
+    };
     float* scratch_scale = bp.take(512);
     auto pack_conv_bn = [&](ConvP& c, const std::string& wname, const std::string& bn, int Cin, int Cout, int k,
                             int stride, int pad) -> int {
         c.Cin = Cin; c.Cout = Cout; c.KH = c.KW = k; c.stride = stride; c.pad = pad;
         c.w = bp.take((size_t)Cout * Cin * k * k);
         c.bias = bp.take(Cout);
+        if (Cin % 64 == 0) want_split(c.split, c.w, Cout, (size_t)Cin * k * k);
         if (fill) {
             // scratch_scale is reused by consecutive launches on one stream: ordered, no hazard
             HIP_TRY(launch_bn_fold(src_of(h, bn + ".weight"), src_of(h, bn + ".bias"), src_of(h, bn + ".running_mean"),
@@ -269,11 +299,15 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
         a.b_in = bp.take((size_t)3 * C);
         a.w_out = bp.take((size_t)C * C);
         a.b_out = bp.take(C);
+        want_split(a.s_in, a.w_in, (size_t)3 * C, C);
+        want_split(a.s_out, a.w_out, C, C);
         if (h->cfg.attn_ff) {
             a.w_ff1 = bp.take((size_t)C * C);
             a.b_ff1 = bp.take(C);
             a.w_ff2 = bp.take((size_t)C * C);
             a.b_ff2 = bp.take(C);
+            want_split(a.s_ff1, a.w_ff1, C, C);
+            want_split(a.s_ff2, a.w_ff2, C, C);
         }
         if (fill) {
             const std::string m = p + mha_name(h);
@@ -320,6 +354,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
                 blk.c1.Cin = inpl; blk.c1.Cout = planes; blk.c1.KH = blk.c1.KW = 3; blk.c1.stride = stride; blk.c1.pad = 1;
                 blk.c1.w = blk.w_both;
                 blk.c1.bias = blk.b_both;
+                if (inpl % 64 == 0) want_split(blk.c1.split, blk.w_both, (size_t)2 * planes, (size_t)9 * inpl);
                 if (fill) {
                     HIP_TRY(launch_bn_fold(src_of(h, p + ".bn1.weight"), src_of(h, p + ".bn1.bias"),
                                            src_of(h, p + ".bn1.running_mean"), src_of(h, p + ".bn1.running_var"),
@@ -374,6 +409,8 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
         d.conv.Cin = d.Cin; d.conv.Cout = d.Cout; d.conv.KH = d.conv.KW = 3; d.conv.stride = 1; d.conv.pad = 1;
         d.conv.w = bp.take((size_t)d.Cout * d.Cin * 9);
         d.conv.bias = bp.take(d.Cout);
+        want_split(d.s_wt, d.wt, (size_t)4 * d.Cin, d.Cin);
+        want_split(d.conv.split, d.conv.w, d.Cout, (size_t)9 * d.Cin);
         if (fill) {
             HIP_TRY(launch_pack_convT(src_of(h, p + ".transpose.weight"), src_of(h, p + ".transpose.bias"), d.wt, d.bt,
                                       d.Cin, d.Cin, st));
@@ -403,6 +440,31 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, bool fill, hipStream_t st) {
     }
     h->enc_inv_freq = bp.take(dim / 2);
     h->dec_div = bp.take(dim / 2);
+    return DANRA_OK;
+}
+
+// The split-operand copies of the registered matrices.  Each is scaled by the power of two that brings its largest
+// |w| into [2^12, 2^13): the low halves of all but vanishing weights then stay normal fp16 numbers.  A matrix that is
+// all zero or holds a non-finite value keeps the fp32 instructions.  Waits for the stream (the maxima are read back).
+int split_registered(danra_handle_s* h, std::vector<SplitJob>& jobs, float* maxima_dev, hipStream_t st) {
+    if (jobs.empty()) return DANRA_OK;
+    for (size_t i = 0; i < jobs.size(); ++i) HIP_TRY(launch_maxabs(jobs[i].w, jobs[i].n, maxima_dev + i, st));
+    std::vector<float> maxima(jobs.size());
+    HIP_TRY(hipMemcpyAsync(maxima.data(), maxima_dev, jobs.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        const float mx = maxima[i];
+        if (!(mx > 0.f) || !(mx <= 3.0e38f)) {
+            jobs[i].dst->wh = nullptr;
+            continue;
+        }
+        int e = 0;
+        (void)frexpf(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
+        int s = 13 - e;                  // 2^s * mx in [2^12, 2^13)
+        s = s > 100 ? 100 : (s < -100 ? -100 : s);
+        jobs[i].dst->inv_scale = ldexpf(1.0f, -s);
+        HIP_TRY(launch_split_weights(jobs[i].w, jobs[i].dst->wh, jobs[i].n, ldexpf(1.0f, s), st));
+    }
     return DANRA_OK;
 }
 
@@ -509,6 +571,14 @@ void choose_split(IGemmArgs& a, const Workspace& ws) {
     a.partial = ws.partial;
 }
 
+int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st);
+
+void use_split(IGemmArgs& a, const SplitW& s) {
+    a.Wh = s.wh;
+    a.wscale = s.inv_scale;
+    a.half = s.wh != nullptr;
+}
+
 IGemmArgs blank_args() {
     IGemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -526,6 +596,7 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     IGemmArgs a = blank_args();
     const int Ho = (Hi + 2 * c.pad - c.KH) / c.stride + 1, Wo = (Wi + 2 * c.pad - c.KW) / c.stride + 1;
     a.A = in; a.W = c.w; a.bias = c.bias; a.res = res; a.tbias = tbias; a.out = out;
+    use_split(a, c.split);
     a.nmean = nmean; a.nrstd = nrstd; a.zeros = h->ws.zeros;
     a.M = B * Ho * Wo; a.N = out2 ? 2 * c.Cout : c.Cout; a.K = c.KH * c.KW * c.Cin;
     a.out2 = out2; a.n_split = out2 ? c.Cout : 0;
@@ -548,7 +619,7 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
             slabs->pix_major = a.pix_major;
         }
     }
-    HIP_TRY(launch_igemm(a, st));
+    RC_TRY(igemm(h, a, st));
     return DANRA_OK;
 }
 
@@ -566,7 +637,7 @@ int run_stem_planes(danra_handle_s* h, const float* const planes[4], int first, 
     a.Hi = H; a.Wi = W; a.Cin = count; a.Ho = H / 2; a.Wo = W / 2; a.KH = 8; a.KW = 8; a.stride = 2; a.pad = 3;
     a.tb_stride = h->tb_width; a.rows_per_img = (H / 2) * (W / 2);
     a.st_mode = ST_ROW; a.ldc = 64;
-    HIP_TRY(launch_igemm(a, st));
+    RC_TRY(igemm(h, a, st));
     return DANRA_OK;
 }
 
@@ -598,6 +669,24 @@ int prof_mark(danra_handle_s* h, hipStream_t st) {
     return DANRA_OK;
 }
 
+// Every implicit GEMM of the forward schedule goes through here: with the family being timed (danra_profile_begin),
+// the launch - its split-K reduction kernel included - is bracketed by events.
+int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
+    const bool timed = h->prof_kind == DANRA_PROF_IGEMM && h->prof_now;
+    if (timed) RC_TRY(prof_mark(h, st));
+    HIP_TRY(launch_igemm(a, st));
+    if (timed) {
+        RC_TRY(prof_mark(h, st));
+        const double fl = 2.0 * (double)a.M * (double)a.N * (double)a.K;
+        h->prof_flops += fl;
+        // the split-operand form issues three fp16 products per algorithmic one
+        const bool split = igemm_uses_split(a);
+        h->prof_exec_flops += split ? 3.0 * fl : fl;
+        if (split) h->prof_split_flops += fl;
+    }
+    return DANRA_OK;
+}
+
 // With ct_w given (64-channel blocks only) the transposed convolution that consumes the block's output is applied
 // in the same kernel as the output projection: ct_out receives [B][2*ct_H][2*ct_W][64] and `out` is not written.
 int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st,
@@ -609,11 +698,12 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     IGemmArgs a = blank_args();
     a.A = x; a.lda = C; a.ln = 1; a.a_mode = A_GEMM;
     a.W = at.w_in; a.bias = at.b_in; a.out = ws.qkv;
+    use_split(a, at.s_in);
     a.M = B * L; a.N = 3 * C; a.K = C;
     a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
     a.qkv_plane = (long long)B * L * C;
     choose_split(a, ws);
-    HIP_TRY(launch_igemm(a, st));
+    RC_TRY(igemm(h, a, st));
     const size_t plane = (size_t)B * L * C;
     const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
     const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
@@ -621,7 +711,9 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
     if (timed) {
         RC_TRY(prof_mark(h, st));
-        h->prof_flops += 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
+        const double fl = 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
+        h->prof_flops += fl;
+        h->prof_exec_flops += (hd == 16 && L % 128 == 0) ? 3.5 * fl : fl;  // head_dim 16: 4 + 3 fp16 instructions per 2 algorithmic products
     }
     // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
     // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
@@ -636,35 +728,39 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     float* attended = ff ? ws.qkv : out;
     IGemmArgs o = blank_args();
     o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;
+    use_split(o, at.s_out);
     o.W = at.w_out; o.bias = at.b_out; o.res = x; o.ldr = C; o.act = (relu && !ff) ? ACT_RELU : ACT_NONE; o.out = attended;
     o.M = B * L; o.N = C; o.K = C; o.st_mode = ST_ROW; o.ldc = C;
     choose_split(o, ws);
-    HIP_TRY(launch_igemm(o, st));
+    RC_TRY(igemm(h, o, st));
     if (!ff) return DANRA_OK;
     IGemmArgs f1 = blank_args();
     f1.A = attended; f1.lda = C; f1.ln = 1; f1.a_mode = A_GEMM;
+    use_split(f1, at.s_ff1);
     f1.W = at.w_ff1; f1.bias = at.b_ff1; f1.act = ACT_GELU; f1.out = ws.obuf;
     f1.M = B * L; f1.N = C; f1.K = C; f1.st_mode = ST_ROW; f1.ldc = C;
     choose_split(f1, ws);
-    HIP_TRY(launch_igemm(f1, st));
+    RC_TRY(igemm(h, f1, st));
     IGemmArgs f2 = blank_args();
     f2.A = ws.obuf; f2.lda = C; f2.a_mode = A_GEMM;
+    use_split(f2, at.s_ff2);
     f2.W = at.w_ff2; f2.bias = at.b_ff2; f2.res = attended; f2.ldr = C; f2.act = relu ? ACT_RELU : ACT_NONE; f2.out = out;
     f2.M = B * L; f2.N = C; f2.K = C; f2.st_mode = ST_ROW; f2.ldc = C;
     choose_split(f2, ws);
-    HIP_TRY(launch_igemm(f2, st));
+    RC_TRY(igemm(h, f2, st));
     return DANRA_OK;
 }
 
 int run_convT(danra_handle_s* h, const float* wt, const float* bt, int C, const float* in, float* out, int B, int Hh,
-              int Ww, hipStream_t st) {
+              int Ww, hipStream_t st, const SplitW* split = nullptr) {
     IGemmArgs a = blank_args();
+    if (split) use_split(a, *split);
     a.A = in; a.lda = C; a.a_mode = A_GEMM;
     a.W = wt; a.bias = bt; a.out = out;
     a.M = B * Hh * Ww; a.N = 4 * C; a.K = C;
     a.st_mode = ST_CONVT; a.ct_C = C; a.ct_H = Hh; a.ct_W = Ww;
     choose_split(a, h->ws);
-    HIP_TRY(launch_igemm(a, st));
+    RC_TRY(igemm(h, a, st));
     return DANRA_OK;
 }
 
@@ -723,7 +819,7 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
     if (!up_ready) {
-        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st));
+        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt));
         HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
     } else {  // the producer of ws.up left its statistics in slices of 32 samples
         HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
@@ -871,6 +967,7 @@ int danra_create(const danra_config_t* cfg, danra_handle_t* out) {
 int danra_destroy(danra_handle_t h) {
     if (!h) return DANRA_OK;
     if (h->arena) (void)hipFree(h->arena);
+    if (h->arena_h) (void)hipFree(h->arena_h);
     drop_step_graph(h->ws);
     if (h->ws.base) (void)hipFree(h->ws.base);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -906,17 +1003,27 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     for (const ParamEntry& p : h->params)
         if (!p.src) return fail(DANRA_ENAME, "state_dict entry '%s' was never set", p.name.c_str());
     hipStream_t st = (hipStream_t)stream;
+    std::vector<SplitJob> jobs;
     if (!h->arena) {
-        Bump probe(nullptr);
-        RC_TRY(layout_and_pack(h, probe, false, st));
+        Bump probe(nullptr), probe_h(nullptr);
+        RC_TRY(layout_and_pack(h, probe, probe_h, jobs, false, st));
         h->arena_bytes = probe.off;
+        h->arena_h_bytes = probe_h.off + jobs.size() * sizeof(float);
         if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) {
             h->arena = nullptr;
             return fail(DANRA_ENOMEM, "weight arena allocation of %zu bytes failed", h->arena_bytes);
         }
+        if (hipMalloc(&h->arena_h, h->arena_h_bytes) != hipSuccess) {
+            (void)hipFree(h->arena);
+            h->arena = nullptr; h->arena_h = nullptr;
+            return fail(DANRA_ENOMEM, "split-weight arena allocation of %zu bytes failed", h->arena_h_bytes);
+        }
+        jobs.clear();
     }
-    Bump bp(h->arena);
-    RC_TRY(layout_and_pack(h, bp, true, st));
+    Bump bp(h->arena), bh(h->arena_h);
+    RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
+    RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
+    for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
     h->freq_dirty = true;
     RC_TRY(upload_freq(h, st));
     for (ParamEntry& p : h->params) p.src = nullptr;  // borrowed pointers are not kept
@@ -998,8 +1105,9 @@ int danra_attention_core_fwd(const float* q, const float* k, const float* v, flo
     return DANRA_OK;
 }
 
-int danra_set_attention_core_mode(int fp32_products) {
+int danra_set_fp32_products(int fp32_products) {
     set_attention_hd16_fp32_products(fp32_products);
+    set_igemm_fp32_products(fp32_products);
     return DANRA_OK;
 }
 
@@ -1224,10 +1332,12 @@ int danra_set_graph_mode(danra_handle_t h, int enable) {
 
 int danra_profile_begin(danra_handle_t h, int kind) {
     if (!h) return fail(DANRA_EINVAL, "null handle");
-    if (kind != DANRA_PROF_FLASH_ATTENTION) return fail(DANRA_EINVAL, "unknown kernel family %d", kind);
+    if (kind != DANRA_PROF_FLASH_ATTENTION && kind != DANRA_PROF_IGEMM) return fail(DANRA_EINVAL, "unknown kernel family %d", kind);
     h->prof_kind = kind;
     h->prof_used = 0;
     h->prof_flops = 0.0;
+    h->prof_exec_flops = 0.0;
+    h->prof_split_flops = 0.0;
     return DANRA_OK;
 }
 
@@ -1246,6 +1356,13 @@ int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, d
     if (total_flops) *total_flops = h->prof_flops;
     h->prof_kind = 0;
     h->prof_used = 0;
+    return DANRA_OK;
+}
+
+int danra_profile_executed(danra_handle_t h, double* executed_flops, double* split_flops) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    if (executed_flops) *executed_flops = h->prof_exec_flops;
+    if (split_flops) *split_flops = h->prof_split_flops;
     return DANRA_OK;
 }
 

@@ -22,6 +22,8 @@ struct IGemmArgs {
     const float* A;
     const float* planes[4];
     const float* W;
+    const float* Wh;      // the same matrix split in fp16 halves (launch_split_weights), or null; used when `half` is set
+    float wscale;         // 2^-s where Wh holds 2^s * W
     const float* bias;
     const float* res;
     const float* tbias;
@@ -47,9 +49,14 @@ struct IGemmArgs {
     int ksplit, chunks_per_split;  // chunks are counted 32-deep
     int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
     int keep_slabs;                // split-K only: leave the slabs in `partial` (no reduction kernel); the consumer sums them
+    int half;                      // != 0: multiply on the fp16 matrix cores with operands split in two fp16 halves (k_igemm HALF)
     int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
+// on != 0: every later launch_igemm multiplies with fp32 matrix instructions whatever `half` says.  Process-wide; for
+// numerical cross-checks.
+void set_igemm_fp32_products(int on);
+bool igemm_uses_split(const IGemmArgs& a);
 
 // Tail of a 64-channel attention block as one kernel (M token rows of 64 floats, every step local to a row):
 //   a = o Wo^T + bo + x;  with W1: a += GELU(LayerNorm(a) W1^T + b1) W2^T + b2 (LayerNorm affine folded into W1/b1);
@@ -180,6 +187,12 @@ hipError_t launch_in_train_bwd(const float* x, const float* dy, const float* sav
                                int planes, int HW, hipStream_t stream);
 
 // ---------------------------------------------------------------- weight packing
+// max |w| over n floats -> *out (one float; not atomic across launches: one launch per destination)
+hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t stream);
+// Split-operand form of a packed weight matrix for k_igemm's HALF variant: n floats (rows of K, K a multiple of 64) ->
+// n float-sized slots; every 64 consecutive weights w become [64 halves hi | 64 halves lo] of scale * w with
+// hi = fp16(scale*w) (rounded towards zero) and lo = fp16(scale*w - hi).  `scale` is a power of two.
+hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream);
 hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                           float* scale, float* shift, int C, hipStream_t stream);
 hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_ohwi, int O, int I, int KH, int KW,

@@ -14,11 +14,29 @@
 // which serialises the prefetch.  LDS rows are padded by 4 floats: 16-byte aligned for
 // ds_write_b128 and conflict-free for the ds_read_b128 fragment reads (lane (i, h) reads
 // k = 8u+4h..8u+4h+3 of row i, so MFMA step r consumes k in {8u+r, 8u+4+r} from both operands).
+#include <type_traits>
+
 #include "danra_kernels.h"
 
 namespace danra {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits of x while |x| is in [2^-3, 2^15); a smaller
+// |x| is kept to an absolute 2^-25 (lo is then an fp16 subnormal, which conversions and matrix cores honour).
+// (hi is x rounded towards zero, one packed conversion per two values; lo is rounded to nearest.)
+__device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    hi[0] = (_Float16)h01[0]; hi[1] = (_Float16)h01[1]; hi[2] = (_Float16)h23[0]; hi[3] = (_Float16)h23[1];
+    lo[0] = (_Float16)(v.x - (float)h01[0]);
+    lo[1] = (_Float16)(v.y - (float)h01[1]);
+    lo[2] = (_Float16)(v.z - (float)h23[0]);
+    lo[3] = (_Float16)(v.w - (float)h23[1]);
+}
 
 static constexpr int BN = 64;
 
@@ -94,7 +112,11 @@ __device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias,
 constexpr int A_CONV_IN = 3;  // kernel-internal: A_CONV with InstanceNorm applied on load
 constexpr int A_GEMM_LN = 4;  // kernel-internal: A_GEMM with LayerNorm applied on load
 
-template <int BM, int KW, int AMODE>
+// HALF: the products run on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulation) with both operands split
+// in two fp16 halves by the staging threads: W A ~ Wh Ah + Wh Al + Wl Ah (the dropped Wl Al term is 2^-22 of a
+// product): three instructions per 16-deep k-step at 16x the fp32 instruction's rate.  An LDS row then holds
+// [BK halves hi | BK halves lo] in the bytes of the BK floats it holds otherwise.
+template <int BM, int KW, int AMODE, bool HALF = false>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     constexpr bool CONV = (AMODE == A_CONV || AMODE == A_CONV_IN);
     constexpr bool NORM = (AMODE == A_CONV_IN);
@@ -102,7 +124,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     constexpr bool LNORM = (AMODE == A_GEMM_LN);
     const int dbg = DANRA_IGEMM_DEBUG ? p.debug : 0;
     constexpr int T = 256 * KW;
-    constexpr int BK = (KW == 4) ? 64 : 32;
+    constexpr int BK = (KW == 4 || HALF) ? 64 : 32;
     constexpr int LDK = BK + 4;
     constexpr int TPR = BK / 4;        // threads per staged row
     constexpr int SWEEP = T / TPR;     // rows staged per sweep
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     __shared__ unsigned long long rowOff[BM];
     __shared__ int rowImg[BM];
     __shared__ int rowOut[BM];   // row of the output tensor (differs from m0 + row in pixel-major order)
+    __shared__ int rangeFlag[3];  // HALF: a value too large for the split / a normal-sized value / a non-zero value was staged
     __shared__ int tapBox[BM / 64][4];  // convolutions, per 64 rows: kh_lo, kh_hi, kw_lo, kw_hi = taps that touch the image for some row
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * BM * LDK;
@@ -124,6 +147,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    if (HALF && tid < 3) rangeFlag[tid] = 0;  // (ordered before its first use by the barriers of the pipeline)
     const int tw = wave & 3;    // which output sub-tile
     const int kpart = wave >> 2;  // which k-blocks of every chunk
     const int m0 = blockIdx.x * BM;
@@ -274,22 +298,28 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     //       and delta = the tap's element offset inside the NHWC window, (kh*Wi + kw)*Cin + cc
     //       and wk = the same position in the weight row, (kh*KW + kw)*Cin + cc
     int t_kh = 0, t_kw = 0, t_cc = 0, delta = 0, wk = 0;
-    if (CONV) {
-        const int q = min(c_begin, total_chunks - 1);
-        const int tap = q / cpt;
-        t_cc = (q - tap * cpt) * BK;
-        t_kh = kh_lo + tap / nkw;
-        t_kw = kw_lo + tap % nkw;
-        delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
-        wk = (t_kh * p.KW + t_kw) * p.Cin + t_cc;
-    }
+    int loaded = 0;       // chunks whose loads have been issued
+    auto rewind = [&]() {  // to the first chunk of this workgroup's K range
+        loaded = 0;
+        if (CONV) {
+            const int q = min(c_begin, total_chunks - 1);
+            const int tap = q / cpt;
+            t_cc = (q - tap * cpt) * BK;
+            t_kh = kh_lo + tap / nkw;
+            t_kw = kw_lo + tap % nkw;
+            delta = (t_kh * p.Wi + t_kw) * p.Cin + t_cc;
+            wk = (t_kh * p.KW + t_kw) * p.Cin + t_cc;
+        }
+    };
     const int row_jump = (p.Wi - nkw) * p.Cin;   // from the box's last tap of a row to its first tap of the next
     const int wrow_jump = (p.KW - nkw) * p.Cin;
     const int kw_end = kw_lo + nkw;
 
-    float4 araw[AR], amu[AR], ars[AR], breg[BR];
+    typedef float v4f __attribute__((ext_vector_type(4)));  // (HIP's float4 is a struct: arrays of it are not always promoted to registers)
+    v4f araw[AR], amu[AR], ars[AR], breg[BR];
+    const float* Wsrc = HALF ? p.Wh : p.W;
     unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
-    int loaded = 0;       // chunks whose loads have been issued
+    float amax = 0.f;     // HALF: largest |value| this thread has staged (range check of the fp16 split)
 
     // -- load phase: issue global loads only; nothing here may consume a loaded value
     auto load_chunk = [&]() {
@@ -299,7 +329,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         if (GEMM) {
             // rows past M re-read row M-1: they only feed output rows that are never stored
 #pragma unroll
-            for (int j = 0; j < AR; ++j) araw[j] = *reinterpret_cast<const float4*>(p.A + (unsigned)(abase[j] + k0));
+            for (int j = 0; j < AR; ++j) araw[j] = *reinterpret_cast<const v4f*>(p.A + (unsigned)(abase[j] + k0));
         } else if (CONV) {
             // a padding tap reads a block of zeros instead (pointer select, the load itself stays unconditional);
             // with InstanceNorm on load its 1/std comes from the zeros too, so (0 - mean) * 0 = 0 needs no select
@@ -307,11 +337,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             for (int j = 0; j < AR; ++j) {
                 const bool ok = (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi && (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
                 const float* src = ok ? p.A + (unsigned)(abase[j] + delta) : p.zeros;
-                araw[j] = *reinterpret_cast<const float4*>(src);
+                araw[j] = *reinterpret_cast<const v4f*>(src);
                 if (NORM) {
                     const float* rs = ok ? p.nrstd + (unsigned)(nbase[j] + t_cc) : p.zeros;
-                    amu[j] = *reinterpret_cast<const float4*>(p.nmean + (unsigned)(nbase[j] + t_cc));
-                    ars[j] = *reinterpret_cast<const float4*>(rs);
+                    amu[j] = *reinterpret_cast<const v4f*>(p.nmean + (unsigned)(nbase[j] + t_cc));
+                    ars[j] = *reinterpret_cast<const v4f*>(rs);
                 }
             }
             if (loaded + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (loads past the end re-read the last one)
@@ -350,17 +380,20 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const float4*>(p.W + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
+        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const v4f*>(Wsrc + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
         ++loaded;
     };
 
     // -- store phase: normalise / zero-fill the staged operand, then write it to LDS buffer `buf`
-    auto store_chunk = [&](int buf) {
+    // (`h` is std::true_type for the split-operand fp16 form, std::false_type for fp32 instructions: a HALF kernel
+    // holds both, see the range check behind the pipeline)
+    auto store_chunk = [&](auto h, int buf) {
+        constexpr bool H = decltype(h)::value;
         float* As = As0 + buf * BM * LDK;
         float* Bs = Bs0 + buf * BN * LDK;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            float4 v = araw[j];
+            float4 v = make_float4(araw[j].x, araw[j].y, araw[j].z, araw[j].w);
             if (LNORM) {
                 v.x = (v.x - rmean[j]) * rrstd[j];
                 v.y = (v.y - rmean[j]) * rrstd[j];
@@ -380,29 +413,66 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 v.z = (m4 & 4u) ? v.z : 0.f;
                 v.w = (m4 & 8u) ? v.w : 0.f;
             }
-            *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
+            if (H) {
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                f16x4 hi, lo;
+                split4(v, hi, lo);
+                _Float16* row = reinterpret_cast<_Float16*>(As + (lrow + SWEEP * j) * LDK);
+                *reinterpret_cast<f16x4*>(row + c4) = hi;
+                *reinterpret_cast<f16x4*>(row + BK + c4) = lo;
+            } else {
+                *reinterpret_cast<float4*>(As + (lrow + SWEEP * j) * LDK + c4) = v;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
+        // (HALF: the weights were split when they were packed - every 64 floats of a row hold [64 halves hi | 64 halves
+        // lo] of those 64 weights, the layout of an LDS row - so their staging is the same plain copy)
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<v4f*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
     };
 
     // -- matrix phase, in two parts: fetch this wave's operand fragments of the chunk in LDS buffer `buf` ...
-    constexpr int NKB = KB / KW;  // k-blocks of a chunk that this wave multiplies
-    float4 fa[NKB], fb[NKB][NT];
-    auto read_fragments = [&](int buf) {
+    // (HALF: a "k-block" is a 16-deep step: lane (i, h) holds halves 16s + 8h .. + 7 of row i, hi and lo)
+    constexpr int NKB32 = KB / KW;                       // k-blocks of a chunk that this wave multiplies: fp32 form
+    constexpr int NKB16 = HALF ? (BK / 16) / KW : 1;     // ... split-operand form
+    static_assert(NKB32 >= 1 && NKB16 >= 1, "more k-parts than k-blocks in a chunk");
+    float4 fa[NKB32], fb[NKB32][NT];
+    f16x8 ha[NKB16][2], hb[NKB16][NT][2];
+    auto read_fragments = [&](auto h, int buf) {
+        constexpr bool H = decltype(h)::value;
+        constexpr int NKB = H ? NKB16 : NKB32;
         const float* As = As0 + buf * BM * LDK + (row0 + fr) * LDK + fh;
         const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
 #pragma unroll
         for (int kbi = 0; kbi < NKB; ++kbi) {
             const int kb = kpart + kbi * KW;
-            fa[kbi] = *reinterpret_cast<const float4*>(As + kb * 8);
+            if (H) {
+                // float offset fh = 4h is half offset 8h; step kb starts at half 16 kb = float 8 kb
+                ha[kbi][0] = *reinterpret_cast<const f16x8*>(As + kb * 8);
+                ha[kbi][1] = *reinterpret_cast<const f16x8*>(As + kb * 8 + BK / 2);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) fb[kbi][t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+                for (int t = 0; t < NT; ++t) {
+                    hb[kbi][t][0] = *reinterpret_cast<const f16x8*>(Bs + t * 32 * LDK + kb * 8);
+                    hb[kbi][t][1] = *reinterpret_cast<const f16x8*>(Bs + t * 32 * LDK + kb * 8 + BK / 2);
+                }
+            } else {
+                fa[kbi] = *reinterpret_cast<const float4*>(As + kb * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fb[kbi][t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+            }
         }
     };
     // ... and multiply them.  Weights are the MFMA A operand: the product comes out transposed, so that a lane owns
     // runs of four consecutive output columns of one output row (16-byte epilogue).
-    auto multiply_fragment = [&](int kbi) {
+    auto multiply_fragment = [&](auto h, int kbi) {
+        if (decltype(h)::value) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][1], ha[kbi][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][0], ha[kbi][1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][0], ha[kbi][0], acc[t], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].x, fa[kbi].x, acc[t], 0, 0, 0);
@@ -412,26 +482,54 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
     };
 
-    load_chunk();    // chunk 0
-    store_chunk(0);
-    load_chunk();    // chunk 1
-    __syncthreads();
-    for (int it = 0; it < n_chunks; ++it) {
-        if (!(dbg & 2)) {
-            read_fragments((dbg & 4) ? 0 : (it & 1));
-            multiply_fragment(0);
-        }
-        // the staging work sits between the first and the remaining matrix instructions of the wave
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4)) store_chunk((it + 1) & 1);  // chunk it+1 (in the last iteration a copy of the last chunk that nobody reads)
-        load_chunk();                               // chunk it+2
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 2)) {
+    auto pipeline = [&](auto h) {
+        constexpr int NKB = decltype(h)::value ? NKB16 : NKB32;
+        rewind();
+        load_chunk();    // chunk 0
+        store_chunk(h, 0);
+        load_chunk();    // chunk 1
+        __syncthreads();
+        for (int it = 0; it < n_chunks; ++it) {
+            if (!(dbg & 2)) {
+                read_fragments(h, (dbg & 4) ? 0 : (it & 1));
+                multiply_fragment(h, 0);
+            }
+            // the staging work sits between the first and the remaining matrix instructions of the wave
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 4)) store_chunk(h, (it + 1) & 1);  // chunk it+1 (in the last iteration a copy of the last chunk that nobody reads)
+            load_chunk();                                  // chunk it+2
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 2)) {
 #pragma unroll
-            for (int kbi = 1; kbi < NKB; ++kbi) multiply_fragment(kbi);
+                for (int kbi = 1; kbi < NKB; ++kbi) multiply_fragment(h, kbi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 4)) __syncthreads();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4)) __syncthreads();
+    };
+    pipeline(std::integral_constant<bool, HALF>{});
+    float out_scale = HALF ? p.wscale : 1.0f;  // the split weights carry a power-of-two scale
+    if (HALF) {
+        // Range check of the split: a staged value of 2^15 or more (or an infinity) does not fit the fp16 high half,
+        // and a tile whose largest value is below 2^-8 would be kept to an absolute 2^-25 only, i.e. to fewer than
+        // 17 bits (an all-zero tile is exact).  Either way the workgroup multiplies its tile again with fp32
+        // instructions, from the fp32 weights.  (A NaN comes out as a NaN in both forms.)
+        const bool too_big = !(amax < 32768.f);
+        const bool normal = amax >= 0.00390625f;
+        if (__any(too_big) && lane == 0) rangeFlag[0] = 1;
+        if (__any(normal) && lane == 0) rangeFlag[1] = 1;
+        if (__any(amax > 0.f) && lane == 0) rangeFlag[2] = 1;
+        __syncthreads();
+        const bool redo = rangeFlag[0] != 0 || (rangeFlag[2] != 0 && rangeFlag[1] == 0);
+        if (__builtin_amdgcn_readfirstlane(redo ? 1 : 0)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            Wsrc = p.W;
+            out_scale = 1.0f;
+            pipeline(std::false_type{});
+        }
     }
 
     // ---- sum the KW partial accumulators (fixed order: k-part 0, 1, 2, 3)
@@ -482,6 +580,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         const int m = m0 + row;
         if (m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(tile + row * LDO + oc4);
+        if (HALF) {
+            v.x *= out_scale; v.y *= out_scale; v.z *= out_scale; v.w *= out_scale;
+        }
         if (p.ksplit > 1) {
             *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = v;
             continue;
@@ -1006,6 +1107,16 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
     return hipGetLastError();
 }
 
+static int g_igemm_fp32_products = 0;
+void set_igemm_fp32_products(int on) { g_igemm_fp32_products = on ? 1 : 0; }
+
+// Whether launch_igemm runs these arguments in the split-operand fp16 form (the row-stationary K = 64 kernel never does).
+bool igemm_uses_split(const IGemmArgs& a) {
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    return a.half && a.Wh && !g_igemm_fp32_products && a.a_mode != A_CONV1 && a.K % 64 == 0 && a.K >= 128 &&
+           (a.a_mode != A_CONV || a.Cin % 64 == 0) && (ks == 1 || a.chunks_per_split % 2 == 0);
+}
+
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     // every store mode keeps runs of four output columns contiguous when its inner extent is a multiple of 4
@@ -1050,20 +1161,28 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
         bm = 64;
         kw = (t64 >= 512) ? 2 : 4;
     }
+    // the split-operand fp16 form walks K in 64-deep chunks: channel counts (and the host's 32-deep split-K chunk
+    // counts) must be multiples of that
+    const bool half = igemm_uses_split(a);
     if (kw == 4 && (a.K % 64 || (ks > 1 && a.chunks_per_split % 2))) kw = 2;
-#define DANRA_LAUNCH_IGEMM(BM_, KW_)                                                                      \
+#define DANRA_LAUNCH_IGEMM(BM_, KW_, H_)                                                                  \
     do {                                                                                                  \
         dim3 grid((a.M + BM_ - 1) / BM_, a.N / BN, ks);                                                   \
-        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM_LN>), grid, dim3(256 * KW_), 0, stream, a); \
-        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM>), grid, dim3(256 * KW_), 0, stream, a);   \
-        else if (a.a_mode == A_CONV && a.nmean) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV_IN>), grid, dim3(256 * KW_), 0, stream, a); \
-        else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV>), grid, dim3(256 * KW_), 0, stream, a);   \
-        else hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1>), grid, dim3(256 * KW_), 0, stream, a);       \
+        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM_LN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
+        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else if (a.a_mode == A_CONV && a.nmean) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV_IN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
+        else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else if (!H_) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1, false>), grid, dim3(256 * KW_), 0, stream, a); \
     } while (0)
-    if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1);
-    else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4);
-    else if (kw == 2) DANRA_LAUNCH_IGEMM(64, 2);
-    else DANRA_LAUNCH_IGEMM(64, 1);
+    if (half) {
+        if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1, true);
+        else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4, true);
+        else if (kw == 2) DANRA_LAUNCH_IGEMM(64, 2, true);
+        else DANRA_LAUNCH_IGEMM(64, 1, true);
+    } else if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1, false);
+    else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4, false);
+    else if (kw == 2) DANRA_LAUNCH_IGEMM(64, 2, false);
+    else DANRA_LAUNCH_IGEMM(64, 1, false);
 #undef DANRA_LAUNCH_IGEMM
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

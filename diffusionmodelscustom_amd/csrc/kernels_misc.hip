@@ -972,6 +972,47 @@ hipError_t launch_pack_conv(const float* w, const float* scale, float* out, int 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_maxabs(const float* __restrict__ w, size_t n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.f;
+    bool bad = false;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const float v = fabsf(w[i]);
+        bad = bad || !(v <= 3.0e38f);  // NaN or infinity
+        m = fmaxf(m, v);
+    }
+    red[threadIdx.x] = bad ? INFINITY : m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_maxabs, dim3(1), dim3(256), 0, stream, w, n, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, _Float16* __restrict__ out, size_t n,
+                                                       float scale) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = w[i] * scale;  // exact: a power of two
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+        const size_t slot = (i >> 6) * 128 + (i & 63);
+        out[slot] = (_Float16)h[0];
+        out[slot + 64] = (_Float16)(v - (float)h[0]);
+    }
+}
+hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream) {
+    if (n % 64) return hipErrorInvalidValue;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), n, scale);
+    return hipGetLastError();
+}
+
 __global__ void k_pack_convT(const float* w, const float* bias, float* wout, float* bout, int Ci, int Co) {
     // w [Ci][Co][2][2] -> wout [(dy*2+dx)*Co + co][ci]; bout = bias tiled over the four sub-pixels
     const size_t total = (size_t)4 * Co * Ci;

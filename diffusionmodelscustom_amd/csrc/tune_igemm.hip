@@ -6,6 +6,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -67,10 +69,18 @@ int main(int argc, char** argv) {
     std::vector<float> h(big);
     srand(1);
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
-    CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(res, h.data(), big * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W, h.data(), (size_t)16 << 20, hipMemcpyHostToDevice));
     CK(hipMemcpy(bias, h.data(), 1 << 16, hipMemcpyHostToDevice));
+    if (const char* e = getenv("DANRA_TUNE_RANGE")) {  // exercise the range check of the split-operand form
+        if (atoi(e) == 1) for (size_t i = 12345; i < big; i += 1000003) h[i] = 3.0e6f;     // values beyond the fp16 range in some tiles
+        if (atoi(e) == 2) for (auto& v : h) v *= 1.0e-4f;                                  // a uniformly tiny operand
+        if (atoi(e) == 3) for (size_t i = 0; i < big; ++i) if ((i / 4096) % 3 == 0) h[i] = 0.f;  // zero stretches
+    }
+    CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice));
+    float* Wh;
+    CK(hipMalloc(&Wh, (size_t)16 << 20));
+    CK(launch_split_weights(W, Wh, (size_t)4 << 20, 4096.f, 0));  // |w| < 1 here
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -79,7 +89,7 @@ int main(int argc, char** argv) {
         const Shape& s = shapes[si];
         IGemmArgs a;
         memset(&a, 0, sizeof(a));
-        a.A = A; a.W = W; a.bias = bias; a.out = out; a.partial = partial; a.zeros = zeros; a.rows_per_img = 1;
+        a.A = A; a.W = W; a.Wh = Wh; a.wscale = 1.0f / 4096.f; a.bias = bias; a.out = out; a.partial = partial; a.zeros = zeros; a.rows_per_img = 1;
         if (s.mode == A_CONV) {
             const int Ho = (s.Hi + 2 * s.pad - s.k) / s.stride + 1, Wo = (s.Wi + 2 * s.pad - s.k) / s.stride + 1;
             a.M = s.B * Ho * Wo; a.N = s.Cout; a.K = s.k * s.k * s.Cin; a.a_mode = A_CONV;
@@ -101,6 +111,7 @@ int main(int argc, char** argv) {
             if (c.ks > 1 && (chunks / c.ks < 4 || (size_t)c.ks * a.M * a.N > ((size_t)16 << 20))) continue;
             if (c.kw == 4 && a.K % 64) continue;
             a.force_bm = c.bm; a.force_kw = c.kw; a.debug = debug;
+            a.half = getenv("DANRA_TUNE_HALF") ? atoi(getenv("DANRA_TUNE_HALF")) : 0;
             a.ksplit = c.ks;
             int cps = (chunks + c.ks - 1) / c.ks;
             if (c.ks > 1) cps += cps & 1;
@@ -114,7 +125,23 @@ int main(int argc, char** argv) {
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / iters;
-            printf("    bm=%3d kw=%d ks=%d  %8.1f us  %6.1f TF/s\n", c.bm, c.kw, a.ksplit, us, flops / us / 1e6);
+            printf("    bm=%3d kw=%d ks=%d  %8.1f us  %6.1f TF/s", c.bm, c.kw, a.ksplit, us, flops / us / 1e6);
+            if (a.half && getenv("DANRA_TUNE_CHECK")) {  // the split-operand result against the fp32 instructions' result
+                const size_t n_out = (size_t)a.M * a.N;
+                std::vector<float> got(n_out), want(n_out);
+                CK(hipMemcpy(got.data(), out, n_out * 4, hipMemcpyDeviceToHost));
+                a.half = 0;
+                CK(launch_igemm(a, 0));
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(want.data(), out, n_out * 4, hipMemcpyDeviceToHost));
+                double err = 0, mx = 0;
+                for (size_t i = 0; i < n_out; ++i) {
+                    err = std::max(err, (double)fabsf(got[i] - want[i]));
+                    mx = std::max(mx, (double)fabsf(want[i]));
+                }
+                printf("   max |half - fp32| = %.3e of max |out| = %.3e (%.2e)", err, mx, err / mx);
+            }
+            printf("\n");
         }
     }
     return 0;

@@ -60,7 +60,7 @@ _SIGNATURES = {
     "danra_noise_image": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_uint64, ctypes.c_uint64, _P]),
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    "danra_set_attention_core_mode": (ctypes.c_int, [ctypes.c_int]),
+    "danra_set_fp32_products": (ctypes.c_int, [ctypes.c_int]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
     "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -74,6 +74,7 @@ _SIGNATURES = {
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                          ctypes.POINTER(ctypes.c_double)]),
+    "danra_profile_executed": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "danra_tbias_width": (ctypes.c_int, [_P]),
     "danra_time_embed": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
     "danra_attention": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
@@ -419,6 +420,14 @@ class UNetEngine:
         _check(self.lib, self.lib.danra_profile_end(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
                "danra_profile_end")
         return ms.value, n.value, fl.value
+
+    def profile_executed(self):
+        """(FLOPs executed by the issued matrix instructions, algorithmic FLOPs that ran in the split-operand fp16 form)
+        of the launches counted by the last profile_begin / profile_end pair."""
+        ex, sp = ctypes.c_double(), ctypes.c_double()
+        _check(self.lib, self.lib.danra_profile_executed(self.handle, ctypes.byref(ex), ctypes.byref(sp)),
+               "danra_profile_executed")
+        return ex.value, sp.value
 
     # ------------------------------------------------------------------ hot path
     def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):

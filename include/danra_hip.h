@@ -159,11 +159,14 @@ int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alp
  * log-sum-exp of every query's scaled scores in the exp2 domain. */
 int danra_attention_core_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, float* lse2_dev,
                              int B, int heads, int L, int head_dim, void* stream);
-/* Numerics switch of the head_dim-16 attention core (no counterpart in the reference; process-wide, affects
- * danra_attention_core_fwd and the sampling path alike): fp32_products != 0 makes every later launch multiply with fp32
- * matrix instructions only (slower), 0 restores the default split-operand fp16 products.  Both forms meet the same
- * tolerance against float64; the switch exists so that a caller can cross-check one against the other. */
-int danra_set_attention_core_mode(int fp32_products);
+/* Numerics switch (no counterpart in the reference; process-wide).  Two kernel families evaluate their fp32 products
+ * on the fp16 matrix cores with every operand split in two fp16 halves (22 significant bits per operand, fp32
+ * accumulation; operands outside the range where that holds are multiplied with fp32 instructions): the head_dim-16
+ * attention core and the implicit GEMM behind the convolutions and projections with K >= 128.  fp32_products != 0
+ * makes every later launch of both (danra_unet_forward, danra_sample, danra_attention_core_fwd, the per-op entry
+ * points) use fp32 matrix instructions only (slower); 0 restores the default.  Both forms meet the same tolerances
+ * against float64; the switch exists so that a caller can cross-check one against the other. */
+int danra_set_fp32_products(int fp32_products);
 /* Gradients of danra_attention_core_fwd: dout_dev = dLoss/dout (layout of out) -> dq, dk, dv (layout of q, k, v).
  * out_dev and lse2_dev are the forward's results; delta_dev: [B*heads][L] scratch.  Two kernels (one accumulates dq
  * over the keys, one dk and dv over the queries), no atomics: results are deterministic. */
@@ -214,8 +217,15 @@ int danra_set_graph_mode(danra_handle_t h, int enable);
  * launch; danra_sample times the launches of every 8th denoise step (that step is enqueued kernel by kernel, the
  * others are replayed from the graph as usual), so that the event records do not slow the loop being measured. */
 #define DANRA_PROF_FLASH_ATTENTION 1 /* the flash attention kernels (head_dim 16; head_dim 32/64 with 2 heads or 1 head) */
+#define DANRA_PROF_IGEMM 2           /* the implicit-GEMM family: every convolution (but the stem's x plane), transposed
+                                      * convolution and projection, each launch with its split-K reduction kernel;
+                                      * algorithmic FLOPs = 2*M*N*K per launch */
 int danra_profile_begin(danra_handle_t h, int kind);
 int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, double* total_flops);
+/* Of the launches counted by the last _begin/_end pair: the FLOPs the issued matrix instructions executed (a
+ * split-operand launch executes three fp16 products per algorithmic fp32 one, the head_dim-16 attention core 3.5) and
+ * the algorithmic FLOPs that ran in the split-operand form.  Either pointer may be NULL. */
+int danra_profile_executed(danra_handle_t h, double* executed_flops, double* split_flops);
 
 /* ---- per-op entry points (unit parity tests of the kernels; NHWC = [B][H][W][C] fp32) ---- */
 

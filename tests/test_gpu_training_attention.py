@@ -267,14 +267,14 @@ def test_training_step_gradients(builder, monkeypatch):
     report = {}
     try:
         for name, fp32_products in (("native core, split-operand fp16 products", 0), ("native core, fp32 products", 1)):
-            lib.danra_set_attention_core_mode(fp32_products)
+            lib.danra_set_fp32_products(fp32_products)
             del fwd[:], bwd[:]
             loss, grads = step(gpu, DEV)
             assert len(fwd) == 4 and len(bwd) == 4, \
                 f"expected the four 64-channel attention blocks on the native core, saw {len(fwd)}/{len(bwd)}"
             report[name] = (abs(loss - want_loss) / abs(want_loss),) + worst(grads)
     finally:
-        lib.danra_set_attention_core_mode(0)
+        lib.danra_set_fp32_products(0)
     monkeypatch.setattr(hip_engine, "attention_core_supported", lambda *a: False)
     del fwd[:]
     loss, grads = step(gpu, DEV)

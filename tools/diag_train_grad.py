@@ -67,11 +67,11 @@ def main():
     results["float64"] = step(as_double(model), "cpu", torch.float64)
     results["torch-cpu"] = step(copy.deepcopy(model), "cpu")
     gpu = copy.deepcopy(model).to("cuda:0")
-    lib.danra_set_attention_core_mode(0)
+    lib.danra_set_fp32_products(0)
     results["native-split"] = step(gpu, "cuda:0")
-    lib.danra_set_attention_core_mode(1)
+    lib.danra_set_fp32_products(1)
     results["native-fp32"] = step(gpu, "cuda:0")
-    lib.danra_set_attention_core_mode(0)
+    lib.danra_set_fp32_products(0)
     supported = hip_engine.attention_core_supported
     hip_engine.attention_core_supported = lambda *a: False
     results["torch-gpu"] = step(gpu, "cuda:0")
