@@ -15,6 +15,7 @@
 //
 // k_attn_small: fallback for any other shape (plain VALU, keys walked in LDS chunks with online softmax).
 #include "danra_kernels.h"
+#include "split_f16.h"
 
 namespace danra {
 
@@ -311,15 +312,18 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 const f16x8 vlo = *reinterpret_cast<const f16x8*>(&Vh[buf][1][hf][(lq * 4 + g) * 8]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    f16x8 phi, plo;
+                    // P = hi + lo, hi rounded towards zero (P <= 2^15 never overflows it): four instructions per pair
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 ph, pl;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const _Float16 hi = (_Float16)s[t][j][r];
-                            phi[4 * j + r] = hi;
-                            plo[4 * j + r] = (_Float16)(s[t][j][r] - (float)hi);
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned h0, l0, h1, l1;
+                        split_pair_f16(s[t][j][0], s[t][j][1], h0, l0);
+                        split_pair_f16(s[t][j][2], s[t][j][3], h1, l1);
+                        ph[2 * j] = h0; ph[2 * j + 1] = h1;
+                        pl[2 * j] = l0; pl[2 * j + 1] = l1;
+                    }
+                    const f16x8 phi = __builtin_bit_cast(f16x8, ph), plo = __builtin_bit_cast(f16x8, pl);
                     if (!(ABL & 16)) {
                         ot2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo, phi, ot2[t], 0, 0, 0);
                         ot[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi, plo, ot[t], 0, 0, 0);

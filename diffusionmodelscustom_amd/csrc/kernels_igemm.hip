@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "danra_kernels.h"
+#include "split_f16.h"
 
 namespace danra {
 
@@ -24,18 +25,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits of x while |x| is in [2^-3, 2^15); a smaller
-// |x| is kept to an absolute 2^-25 (lo is then an fp16 subnormal, which conversions and matrix cores honour).
-// (hi is x rounded towards zero, one packed conversion per two values; lo is rounded to nearest.)
+// The four values of a staged float4 as fp16 halves (see split_pair_f16).
 __device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
-    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
-    const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-    hi[0] = (_Float16)h01[0]; hi[1] = (_Float16)h01[1]; hi[2] = (_Float16)h23[0]; hi[3] = (_Float16)h23[1];
-    lo[0] = (_Float16)(v.x - (float)h01[0]);
-    lo[1] = (_Float16)(v.y - (float)h01[1]);
-    lo[2] = (_Float16)(v.z - (float)h23[0]);
-    lo[3] = (_Float16)(v.w - (float)h23[1]);
+    unsigned h[2], l[2];
+    split_pair_f16(v.x, v.y, h[0], l[0]);
+    split_pair_f16(v.z, v.w, h[1], l[1]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(f16x4, (u32x2){h[0], h[1]});
+    lo = __builtin_bit_cast(f16x4, (u32x2){l[0], l[1]});
 }
 
 static constexpr int BN = 64;
@@ -103,6 +100,8 @@ __device__ __forceinline__ float finish(const IGemmArgs& p, float v, float bias,
     return v;
 }
 
+__device__ __forceinline__ float component(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
 // Timing ablations (tune_igemm builds this file with -DDANRA_IGEMM_DEBUG=1; results are then wrong when
 // p.debug != 0).  In the library build the flags are compiled out of the loop.
 #ifndef DANRA_IGEMM_DEBUG
@@ -116,25 +115,38 @@ constexpr int A_GEMM_LN = 4;  // kernel-internal: A_GEMM with LayerNorm applied 
 // in two fp16 halves by the staging threads: W A ~ Wh Ah + Wh Al + Wl Ah (the dropped Wl Al term is 2^-22 of a
 // product): three instructions per 16-deep k-step at 16x the fp32 instruction's rate.  An LDS row then holds
 // [BK halves hi | BK halves lo] in the bytes of the BK floats it holds otherwise.
-template <int BM, int KW, int AMODE, bool HALF = false>
-__global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
+// SPEC (with HALF, KW = 4 and BM = 64 only): twelve waves in two roles.  Waves 0-3 only multiply: each owns the WHOLE
+// 64x64 tile (four accumulator tiles) for one of the four 16-deep k-steps of every chunk, so a fragment read from LDS
+// feeds two matrix instructions per term instead of one (the LDS read traffic of the 4 sub-tiles x 4 k-parts
+// arrangement is twice as high, and with the split operands it is the largest item of an iteration).  Waves 4-11 only
+// stage (global loads, conversion to fp16 halves, LDS writes).  Waves that all do both go through those phases
+// together - matrix cores idle while everybody converts, and the other way round; with the roles apart the phases
+// of a SIMD's waves overlap.  The four partial tiles are summed in the epilogue (fixed order), by all twelve waves.
+template <int BM, int KW, int AMODE, bool HALF = false, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs p) {
+    static_assert(!SPEC || (HALF && KW == 4 && BM == 64), "wave roles exist for the 64-row split-operand kernel only");
+    constexpr int KWC = KW;                    // k-parts among the multiplying waves
+    constexpr int TS = SPEC ? 512 : 256 * KW;  // staging threads
     constexpr bool CONV = (AMODE == A_CONV || AMODE == A_CONV_IN);
     constexpr bool NORM = (AMODE == A_CONV_IN);
     constexpr bool GEMM = (AMODE == A_GEMM || AMODE == A_GEMM_LN);
     constexpr bool LNORM = (AMODE == A_GEMM_LN);
     const int dbg = DANRA_IGEMM_DEBUG ? p.debug : 0;
-    constexpr int T = 256 * KW;
+    constexpr int T = SPEC ? 768 : 256 * KW;
     constexpr int BK = (KW == 4 || HALF) ? 64 : 32;
     constexpr int LDK = BK + 4;
     constexpr int TPR = BK / 4;        // threads per staged row
-    constexpr int SWEEP = T / TPR;     // rows staged per sweep
+    constexpr int SWEEP = TS / TPR;    // rows staged per sweep
     constexpr int AR = BM / SWEEP;     // float4 A loads per thread and chunk
     constexpr int BR = BN / SWEEP;     // float4 B loads per thread and chunk
     constexpr int NT = (BM == 128) ? 2 : 1;
+    constexpr int NTR = SPEC ? 2 : 1;   // 32x32 accumulator tiles of a multiplying wave: rows x columns
+    constexpr int NTC = SPEC ? 2 : NT;
+    constexpr int NACC = NTR * NTC;
     constexpr int KB = BK / 8;         // 8-deep k-blocks per chunk
     static_assert(AR >= 1 && BR >= 1, "tile/threads mismatch");
     constexpr int STAGE_FLOATS = 2 * (BM + BN) * LDK;
-    constexpr int RED_FLOATS = (KW - 1) * 4 * NT * 16 * 64;
+    constexpr int RED_FLOATS = SPEC ? 4 * BM * (BN + 4) : (KWC - 1) * 4 * NT * 16 * 64;
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS];
     __shared__ unsigned long long rowOff[BM];
     __shared__ int rowImg[BM];
@@ -148,12 +160,27 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     if (HALF && tid < 3) rangeFlag[tid] = 0;  // (ordered before its first use by the barriers of the pipeline)
+    // Timing build only, debug bit 64: workgroup 0 leaves clock readings of the kernel's phases behind the per-iteration ones
+    auto phase_stamp = [&](int k) {
+#if DANRA_IGEMM_DEBUG
+        if ((dbg & 64) && blockIdx.x == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) reinterpret_cast<unsigned long long*>(p.partial)[16 * 64 * 4 + wave * 8 + k] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+    };
+    phase_stamp(0);
     const int tw = wave & 3;    // which output sub-tile
-    const int kpart = wave >> 2;  // which k-blocks of every chunk
+    const int kpart = SPEC ? (wave & 3) : (wave >> 2);  // which k-blocks of every chunk
+    // SPEC: waves 4-11 stage, waves 0-3 multiply (a wave-uniform scalar; without SPEC every wave does both)
+    const bool stager = !SPEC || __builtin_amdgcn_readfirstlane(wave) >= 4;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int row0 = (BM == 128) ? tw * 32 : (tw >> 1) * 32;
-    const int col0 = (BM == 128) ? 0 : (tw & 1) * 32;
+    const int row0 = SPEC ? 0 : (BM == 128) ? tw * 32 : (tw >> 1) * 32;
+    const int col0 = (SPEC || BM == 128) ? 0 : (tw & 1) * 32;
 
     // ---- output row table (a few integer divisions per row, done once per block)
     if (tid < BM) {
@@ -208,8 +235,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     }
 
     // ---- per-thread staging geometry
-    const int lrow = tid / TPR;  // + SWEEP*j
-    const int c4 = (tid % TPR) * 4;
+    const int stid = SPEC ? ((tid - 256) & 511) : tid;  // index among the staging threads
+    const int lrow = stid / TPR;  // + SWEEP*j
+    const int c4 = (stid % TPR) * 4;
     // Row j of this thread: 32-bit element offsets (every tensor of the network is < 2^31 elements).
     //   conv : abase = offset of tap (0,0) of the row's window (may point before the row's image for
     //          padded taps: only used when the tap is in bounds)
@@ -250,7 +278,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
 
     // ---- LayerNorm statistics of this thread's rows (two-pass, fp32) over the whole K = channel
     //      count: TPR lanes share a row, same thread->row mapping as the staging loads
-    if (LNORM) {
+    if (LNORM && stager) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const float* src = p.A + abase[j];
@@ -275,9 +303,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
     }
 
-    f32x16 acc[NT];
+    f32x16 acc[NACC];  // tile (tr, tc) at index tr * NTC + tc
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -316,20 +344,22 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     const int kw_end = kw_lo + nkw;
 
     typedef float v4f __attribute__((ext_vector_type(4)));  // (HIP's float4 is a struct: arrays of it are not always promoted to registers)
-    v4f araw[AR], amu[AR], ars[AR], breg[BR];
+    // two sets of staging registers: the split-operand pipeline keeps the loads of two chunks in flight (set = chunk & 1)
+    v4f araw[2][AR], amu[2][AR], ars[2][AR], breg[2][BR];
     const float* Wsrc = HALF ? p.Wh : p.W;
-    unsigned okmask = 0;  // stem only: 4 bits per staged row, which of the four elements are real data
+    unsigned okmask[2] = {0, 0};  // stem only: 4 bits per staged row, which of the four elements are real data
     float amax = 0.f;     // HALF: largest |value| this thread has staged (range check of the fp16 split)
 
     // -- load phase: issue global loads only; nothing here may consume a loaded value
-    auto load_chunk = [&]() {
+    auto load_chunk = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         const int k0 = (dbg & 1) ? c_begin * BK : min(c_begin + loaded, c_end - 1) * BK;  // GEMM, stem
         const int wk_load = wk;
-        okmask = 0;
+        okmask[SET] = 0;
         if (GEMM) {
             // rows past M re-read row M-1: they only feed output rows that are never stored
 #pragma unroll
-            for (int j = 0; j < AR; ++j) araw[j] = *reinterpret_cast<const v4f*>(p.A + (unsigned)(abase[j] + k0));
+            for (int j = 0; j < AR; ++j) araw[SET][j] = *reinterpret_cast<const v4f*>(p.A + (unsigned)(abase[j] + k0));
         } else if (CONV) {
             // a padding tap reads a block of zeros instead (pointer select, the load itself stays unconditional);
             // with InstanceNorm on load its 1/std comes from the zeros too, so (0 - mean) * 0 = 0 needs no select
@@ -337,11 +367,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
             for (int j = 0; j < AR; ++j) {
                 const bool ok = (unsigned)(riy[j] + t_kh) < (unsigned)p.Hi && (unsigned)(rix[j] + t_kw) < (unsigned)p.Wi;
                 const float* src = ok ? p.A + (unsigned)(abase[j] + delta) : p.zeros;
-                araw[j] = *reinterpret_cast<const v4f*>(src);
+                araw[SET][j] = *reinterpret_cast<const v4f*>(src);
                 if (NORM) {
                     const float* rs = ok ? p.nrstd + (unsigned)(nbase[j] + t_cc) : p.zeros;
-                    amu[j] = *reinterpret_cast<const v4f*>(p.nmean + (unsigned)(nbase[j] + t_cc));
-                    ars[j] = *reinterpret_cast<const v4f*>(rs);
+                    amu[SET][j] = *reinterpret_cast<const v4f*>(p.nmean + (unsigned)(nbase[j] + t_cc));
+                    ars[SET][j] = *reinterpret_cast<const v4f*>(rs);
                 }
             }
             if (loaded + 1 < n_chunks && !(dbg & 1)) {  // advance to the next chunk (loads past the end re-read the last one)
@@ -369,31 +399,32 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 const bool rowok = rvalid[j] && iy >= 0 && iy < p.Hi;
                 const float* rowp = src + (rb[j] * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi;
                 const int ix0 = rix[j] + kw;
-                araw[j].x = rowp[min(max(ix0, 0), p.Wi - 1)];
-                araw[j].y = rowp[min(max(ix0 + 1, 0), p.Wi - 1)];
-                araw[j].z = rowp[min(max(ix0 + 2, 0), p.Wi - 1)];
-                araw[j].w = rowp[min(max(ix0 + 3, 0), p.Wi - 1)];
+                araw[SET][j].x = rowp[min(max(ix0, 0), p.Wi - 1)];
+                araw[SET][j].y = rowp[min(max(ix0 + 1, 0), p.Wi - 1)];
+                araw[SET][j].z = rowp[min(max(ix0 + 2, 0), p.Wi - 1)];
+                araw[SET][j].w = rowp[min(max(ix0 + 3, 0), p.Wi - 1)];
                 unsigned m4 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m4 |= (rowok && ix0 + q >= 0 && ix0 + q < p.Wi) ? (1u << q) : 0u;
-                okmask |= m4 << (4 * j);
+                okmask[SET] |= m4 << (4 * j);
             }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) breg[j] = *reinterpret_cast<const v4f*>(Wsrc + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
+        for (int j = 0; j < BR; ++j) breg[SET][j] = *reinterpret_cast<const v4f*>(Wsrc + (unsigned)(wbase[j] + (CONV ? wk_load : k0)));
         ++loaded;
     };
 
     // -- store phase: normalise / zero-fill the staged operand, then write it to LDS buffer `buf`
     // (`h` is std::true_type for the split-operand fp16 form, std::false_type for fp32 instructions: a HALF kernel
     // holds both, see the range check behind the pipeline)
-    auto store_chunk = [&](auto h, int buf) {
+    auto store_chunk = [&](auto h, auto set_tag, int buf) {
         constexpr bool H = decltype(h)::value;
+        constexpr int SET = decltype(set_tag)::value;
         float* As = As0 + buf * BM * LDK;
         float* Bs = Bs0 + buf * BN * LDK;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            float4 v = make_float4(araw[j].x, araw[j].y, araw[j].z, araw[j].w);
+            float4 v = make_float4(araw[SET][j].x, araw[SET][j].y, araw[SET][j].z, araw[SET][j].w);
             if (LNORM) {
                 v.x = (v.x - rmean[j]) * rrstd[j];
                 v.y = (v.y - rmean[j]) * rrstd[j];
@@ -401,13 +432,13 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
                 v.w = (v.w - rmean[j]) * rrstd[j];
             }
             if (NORM) {
-                v.x = (v.x - amu[j].x) * ars[j].x;
-                v.y = (v.y - amu[j].y) * ars[j].y;
-                v.z = (v.z - amu[j].z) * ars[j].z;
-                v.w = (v.w - amu[j].w) * ars[j].w;
+                v.x = (v.x - amu[SET][j].x) * ars[SET][j].x;
+                v.y = (v.y - amu[SET][j].y) * ars[SET][j].y;
+                v.z = (v.z - amu[SET][j].z) * ars[SET][j].z;
+                v.w = (v.w - amu[SET][j].w) * ars[SET][j].w;
             }
             if (AMODE == A_CONV1) {
-                const unsigned m4 = okmask >> (4 * j);
+                const unsigned m4 = okmask[SET] >> (4 * j);
                 v.x = (m4 & 1u) ? v.x : 0.f;
                 v.y = (m4 & 2u) ? v.y : 0.f;
                 v.z = (m4 & 4u) ? v.z : 0.f;
@@ -427,16 +458,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
 #pragma unroll
         // (HALF: the weights were split when they were packed - every 64 floats of a row hold [64 halves hi | 64 halves
         // lo] of those 64 weights, the layout of an LDS row - so their staging is the same plain copy)
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<v4f*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[j];
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<v4f*>(Bs + (lrow + SWEEP * j) * LDK + c4) = breg[SET][j];
     };
 
     // -- matrix phase, in two parts: fetch this wave's operand fragments of the chunk in LDS buffer `buf` ...
     // (HALF: a "k-block" is a 16-deep step: lane (i, h) holds halves 16s + 8h .. + 7 of row i, hi and lo)
-    constexpr int NKB32 = KB / KW;                       // k-blocks of a chunk that this wave multiplies: fp32 form
-    constexpr int NKB16 = HALF ? (BK / 16) / KW : 1;     // ... split-operand form
+    constexpr int NKB32 = KB / KWC;                      // k-blocks of a chunk that this wave multiplies: fp32 form
+    constexpr int NKB16 = HALF ? (BK / 16) / KWC : 1;    // ... split-operand form
     static_assert(NKB32 >= 1 && NKB16 >= 1, "more k-parts than k-blocks in a chunk");
-    float4 fa[NKB32], fb[NKB32][NT];
-    f16x8 ha[NKB16][2], hb[NKB16][NT][2];
+    float4 fa[NKB32][NTR], fb[NKB32][NTC];
+    f16x8 ha[NKB16][NTR][2], hb[NKB16][NTC][2];
     auto read_fragments = [&](auto h, int buf) {
         constexpr bool H = decltype(h)::value;
         constexpr int NKB = H ? NKB16 : NKB32;
@@ -444,72 +475,151 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         const float* Bs = Bs0 + buf * BN * LDK + (col0 + fr) * LDK + fh;
 #pragma unroll
         for (int kbi = 0; kbi < NKB; ++kbi) {
-            const int kb = kpart + kbi * KW;
+            const int kb = kpart + kbi * KWC;
             if (H) {
                 // float offset fh = 4h is half offset 8h; step kb starts at half 16 kb = float 8 kb
-                ha[kbi][0] = *reinterpret_cast<const f16x8*>(As + kb * 8);
-                ha[kbi][1] = *reinterpret_cast<const f16x8*>(As + kb * 8 + BK / 2);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
+                for (int t = 0; t < NTR; ++t) {
+                    ha[kbi][t][0] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDK + kb * 8);
+                    ha[kbi][t][1] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDK + kb * 8 + BK / 2);
+                }
+#pragma unroll
+                for (int t = 0; t < NTC; ++t) {
                     hb[kbi][t][0] = *reinterpret_cast<const f16x8*>(Bs + t * 32 * LDK + kb * 8);
                     hb[kbi][t][1] = *reinterpret_cast<const f16x8*>(Bs + t * 32 * LDK + kb * 8 + BK / 2);
                 }
             } else {
-                fa[kbi] = *reinterpret_cast<const float4*>(As + kb * 8);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) fb[kbi][t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
+                for (int t = 0; t < NTR; ++t) fa[kbi][t] = *reinterpret_cast<const float4*>(As + t * 32 * LDK + kb * 8);
+#pragma unroll
+                for (int t = 0; t < NTC; ++t) fb[kbi][t] = *reinterpret_cast<const float4*>(Bs + t * 32 * LDK + kb * 8);
             }
         }
     };
     // ... and multiply them.  Weights are the MFMA A operand: the product comes out transposed, so that a lane owns
     // runs of four consecutive output columns of one output row (16-byte epilogue).
     auto multiply_fragment = [&](auto h, int kbi) {
+        // (term by term over the wave's tiles: consecutive instructions then write different accumulators; per
+        // accumulator the order of the sum is lo-hi, hi-lo, hi-hi / x, y, z, w whatever the number of tiles)
         if (decltype(h)::value) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][1], ha[kbi][0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][0], ha[kbi][1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][t][0], ha[kbi][0], acc[t], 0, 0, 0);
-            }
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < NTC; ++tc)
+                        acc[tr * NTC + tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb[kbi][tc][term == 0 ? 1 : 0], ha[kbi][tr][term == 1 ? 1 : 0],
+                                                                                    acc[tr * NTC + tc], 0, 0, 0);
             return;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].x, fa[kbi].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].y, fa[kbi].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].z, fa[kbi].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kbi][t].w, fa[kbi].w, acc[t], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < NTC; ++tc)
+                    acc[tr * NTC + tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(component(fb[kbi][tc], e), component(fa[kbi][tr], e), acc[tr * NTC + tc], 0, 0, 0);
     };
 
-    auto pipeline = [&](auto h) {
-        constexpr int NKB = decltype(h)::value ? NKB16 : NKB32;
-        rewind();
-        load_chunk();    // chunk 0
-        store_chunk(h, 0);
-        load_chunk();    // chunk 1
-        __syncthreads();
-        for (int it = 0; it < n_chunks; ++it) {
-            if (!(dbg & 2)) {
-                read_fragments(h, (dbg & 4) ? 0 : (it & 1));
-                multiply_fragment(h, 0);
-            }
-            // the staging work sits between the first and the remaining matrix instructions of the wave
+    // one iteration: multiply chunk `it` (LDS buffer it & 1), write chunk it+1 from register set SET into the other
+    // buffer and reuse that set for the loads of the chunk that is PF further on
+    // (`role`: 0 = this wave stages and multiplies, 1 = it only stages, 2 = it only multiplies)
+    // Timing build only, debug bit 64: workgroup 0 leaves clock readings in p.partial, four per wave and iteration.
+    auto stamp = [&](int it, int k) {
+#if DANRA_IGEMM_DEBUG
+        if ((dbg & 64) && blockIdx.x == 0 && it < 64) {
             __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 4)) store_chunk(h, (it + 1) & 1);  // chunk it+1 (in the last iteration a copy of the last chunk that nobody reads)
-            load_chunk();                                  // chunk it+2
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): what was issued so far has landed (vmcnt, expcnt left alone)
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) reinterpret_cast<unsigned long long*>(p.partial)[(wave * 64 + it) * 4 + k] = t;
             __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 2)) {
-#pragma unroll
-                for (int kbi = 1; kbi < NKB; ++kbi) multiply_fragment(h, kbi);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 4)) __syncthreads();
         }
+#endif
     };
-    pipeline(std::integral_constant<bool, HALF>{});
+    auto iteration = [&](auto h, auto set_tag, auto load_tag, int it, auto role) {
+        constexpr int NKB = decltype(h)::value ? NKB16 : NKB32;
+        constexpr int ROLE = decltype(role)::value;
+        if (ROLE == 1) {
+            // (loads issued ahead of the conversions and LDS writes, or by half of the staging waves only, took longer)
+            stamp(it, 0);
+            store_chunk(h, set_tag, (it + 1) & 1);
+            stamp(it, 1);
+            load_chunk(load_tag);
+            stamp(it, 2);
+            __syncthreads();
+            stamp(it, 3);
+            return;
+        }
+        if (ROLE == 2) {
+            stamp(it, 0);
+            read_fragments(h, it & 1);
+            stamp(it, 1);
+#pragma unroll
+            for (int kbi = 0; kbi < NKB; ++kbi) multiply_fragment(h, kbi);
+            stamp(it, 2);
+            __syncthreads();
+            stamp(it, 3);
+            return;
+        }
+        stamp(it, 0);
+        if (!(dbg & 2)) {
+            read_fragments(h, (dbg & 4) ? 0 : (it & 1));
+            multiply_fragment(h, 0);
+        }
+        // the staging work sits between the first and the remaining matrix instructions of the wave
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(it, 1);
+        if (!(dbg & 4)) store_chunk(h, set_tag, (it + 1) & 1);  // (in the last iteration a copy of the last chunk that nobody reads)
+        stamp(it, 2);
+        if (!(dbg & 16)) load_chunk(load_tag);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int kbi = 1; kbi < NKB; ++kbi) multiply_fragment(h, kbi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(it, 3);
+        if (!(dbg & 4)) __syncthreads();
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    auto pipeline = [&](auto h, auto role) {
+        constexpr bool stager = decltype(role)::value != 2;
+        phase_stamp(1);
+        rewind();
+        if (decltype(h)::value && decltype(role)::value != 0) {
+            // A staging-only wave has registers to spare and a short iteration: it keeps the loads of TWO chunks in
+            // flight.  Chunk c goes through register set c & 1; iteration `it` stores chunk it+1 and issues the
+            // loads of chunk it+3.  (For waves that also multiply the second set bought nothing and cost the
+            // 8-wave kernel its second workgroup per CU.)
+            if (stager) {
+                load_chunk(Set0{});     // chunk 0
+                store_chunk(h, Set0{}, 0);
+                load_chunk(Set1{});     // chunk 1
+                load_chunk(Set0{});     // chunk 2
+            }
+            __syncthreads();
+            phase_stamp(2);
+            for (int it = 0; it < n_chunks; it += 2) {
+                iteration(h, Set1{}, Set1{}, it, role);
+                if (it + 1 < n_chunks) iteration(h, Set0{}, Set0{}, it + 1, role);
+            }
+            phase_stamp(3);
+            return;
+        }
+        if (stager) {
+            load_chunk(Set0{});    // chunk 0
+            store_chunk(h, Set0{}, 0);
+            load_chunk(Set0{});    // chunk 1
+        }
+        __syncthreads();
+        for (int it = 0; it < n_chunks; ++it) iteration(h, Set0{}, Set0{}, it, role);  // stores chunk it+1, loads chunk it+2
+    };
     float out_scale = HALF ? p.wscale : 1.0f;  // the split weights carry a power-of-two scale
-    if (HALF) {
+    // The whole product, as one role sees it.  Every role goes through the same sequence of barriers.
+    auto product = [&](auto role) {
+        pipeline(std::integral_constant<bool, HALF>{}, role);
+        if (!HALF) return;
         // Range check of the split: a staged value of 2^15 or more (or an infinity) does not fit the fp16 high half,
         // and a tile whose largest value is below 2^-8 would be kept to an absolute 2^-25 only, i.e. to fewer than
         // 17 bits (an all-zero tile is exact).  Either way the workgroup multiplies its tile again with fp32
@@ -523,48 +633,71 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         const bool redo = rangeFlag[0] != 0 || (rangeFlag[2] != 0 && rangeFlag[1] == 0);
         if (__builtin_amdgcn_readfirstlane(redo ? 1 : 0)) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NACC; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             Wsrc = p.W;
             out_scale = 1.0f;
-            pipeline(std::false_type{});
+            pipeline(std::false_type{}, role);
         }
-    }
+    };
+    if (!SPEC) product(std::integral_constant<int, 0>{});
 
-    // ---- sum the KW partial accumulators (fixed order: k-part 0, 1, 2, 3)
-    if (KW > 1) {
-        // the trailing __syncthreads() of the loop has retired every read of the staging buffers
-        float* red = smem;
-        if (kpart > 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[((((kpart - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
-        }
-        __syncthreads();
-        if (kpart > 0) return;
-#pragma unroll
-        for (int kp = 1; kp < KW; ++kp)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] += red[((((kp - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane];
-    }
-
-    // ---- epilogue.  acc[t][r] = out[row m0 + row0 + (lane & 31)][column n0 + col0 + 32t + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)].
-    // The tile goes through LDS once so that 16 consecutive lanes own one whole 64-column output row: residual
-    // loads and stores are then 256-byte contiguous per row, and a thread needs one column offset for all its rows.
+    // ---- sum the partial accumulators of the k-parts (fixed order: k-part 0, 1, 2, 3)
     constexpr int LDO = BN + 4;
     float* tile = smem;
-    __syncthreads();  // (the waves still alive) every read of the staging / reduction buffers has retired
+    if (SPEC) {
+        // every multiplying wave leaves its whole partial tile in LDS; the epilogue below adds the four up.  (The
+        // trailing __syncthreads() of the loop has retired every read of the staging buffers.)
+        if (stager) {
+            product(std::integral_constant<int, 1>{});
+        } else {
+            product(std::integral_constant<int, 2>{});
+            float* mine = smem + kpart * BM * LDO;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+            for (int tr = 0; tr < NTR; ++tr)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(tile + (row0 + fr) * LDO + col0 + t * 32 + 8 * g + fh) =
-                make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-    __syncthreads();
+                for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(mine + (tr * 32 + fr) * LDO + tc * 32 + 8 * g + fh) =
+                            make_float4(acc[tr * NTC + tc][4 * g], acc[tr * NTC + tc][4 * g + 1], acc[tr * NTC + tc][4 * g + 2], acc[tr * NTC + tc][4 * g + 3]);
+        }
+        __syncthreads();
+    } else {
+        if (KWC > 1) {
+            // the trailing __syncthreads() of the loop has retired every read of the staging buffers
+            float* red = smem;
+            if (kpart > 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((((kpart - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (kpart > 0) return;  // (a wave that has ended no longer counts at a barrier)
+#pragma unroll
+            for (int kp = 1; kp < KWC; ++kp)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += red[((((kp - 1) * 4 + tw) * NT + t) * 16 + r) * 64 + lane];
+        }
+
+        // ---- epilogue.  acc[t][r] = out[row m0 + row0 + (lane & 31)][column n0 + col0 + 32t + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)].
+        // The tile goes through LDS once so that 16 consecutive lanes own one whole 64-column output row: residual
+        // loads and stores are then 256-byte contiguous per row, and a thread needs one column offset for all its rows.
+        __syncthreads();  // (the waves still alive) every read of the staging / reduction buffers has retired
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(tile + (row0 + fr) * LDO + col0 + t * 32 + 8 * g + fh) =
+                    make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        __syncthreads();
+    }
+    constexpr int ESWEEP = SPEC ? T / 16 : 16;  // output rows per sweep of the threads that are left
+    phase_stamp(4);
     const int oc4 = (tid & 15) * 4;
     const int n = n0 + oc4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -575,11 +708,19 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
     float* const outp = second ? p.out2 : p.out;
     const unsigned long long co = col_offset(p, second ? n - p.n_split : n);
 #pragma unroll
-    for (int j = 0; j < BM / 16; ++j) {
-        const int row = (tid >> 4) + 16 * j;
+    for (int j = 0; j < (BM + ESWEEP - 1) / ESWEEP; ++j) {
+        const int row = (tid >> 4) + ESWEEP * j;
         const int m = m0 + row;
+        if ((BM % ESWEEP) && row >= BM) continue;
         if (m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(tile + row * LDO + oc4);
+        if (SPEC) {
+#pragma unroll
+            for (int kp = 1; kp < 4; ++kp) {
+                const float4 o = *reinterpret_cast<const float4*>(tile + (kp * BM + row) * LDO + oc4);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+        }
         if (HALF) {
             v.x *= out_scale; v.y *= out_scale; v.z *= out_scale; v.w *= out_scale;
         }
@@ -603,32 +744,53 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IGemmArgs p) {
         }
         *reinterpret_cast<float4*>(outp + rowOff[row] + co) = v;
     }
+#if DANRA_IGEMM_DEBUG
+    if (dbg & 64) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores have been acknowledged
+#endif
+    phase_stamp(5);
 }
 
 // Sums the split-K slabs in slab order (bitwise reproducible) and applies the epilogue.
-// One thread per four consecutive columns of one row.
+// One thread per four consecutive columns of one row (they lie on one side of n_split and are contiguous in every
+// store mode: launch_igemm checks).  A thread has one or two such groups, so the kernel is a chain of memory
+// latencies: every load of a group - up to eight slabs, bias, residual, embedding bias - is issued before the first
+// value is used (with the slab loads inside a loop of unknown length each waited for the one before: 5-6 us per
+// launch on the 4x4 and 2x2 maps, against 3 with the loads in flight together).
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
     const size_t total4 = (size_t)p.M * p.N / 4;
     const size_t slab = (size_t)p.M * p.N;
+    constexpr int KS = 8;  // slabs loaded together
     for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
         const size_t idx = i4 * 4;
-        float4 v = *reinterpret_cast<const float4*>(p.partial + idx);
-        for (int z = 1; z < p.ksplit; ++z) {
-            const float4 o = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + idx);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        const int mt = (int)(idx / p.N);  // row of the GEMM; the slabs are in that order
-        const int n = (int)(idx - (size_t)mt * p.N);
+        float4 part[KS];
+#pragma unroll
+        for (int z = 0; z < KS; ++z)
+            if (z < p.ksplit) part[z] = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + idx);
+        const int mt = (int)((unsigned)idx / (unsigned)p.N);  // row of the GEMM; the slabs are in that order (M N < 2^31: launch_igemm checks)
+        const int n = (int)((unsigned)idx - (unsigned)mt * (unsigned)p.N);
         const int m = out_row(p, mt);
         int img;
         const unsigned long long ro = row_offset(p, m, img);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+        const bool second = p.out2 && n >= p.n_split;  // second output: bias only
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), res = bias, tb = bias;
+        if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.res && !second) res = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldr + n);
+        if (p.tbias && !second) tb = *reinterpret_cast<const float4*>(p.tbias + (size_t)img * p.tb_stride + n);
+        float4 v = part[0];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float bias = p.bias ? p.bias[n + q] : 0.f;
-            const bool second = p.out2 && n + q >= p.n_split;
-            (second ? p.out2 : p.out)[ro + col_offset(p, second ? n + q - p.n_split : n + q)] = finish(p, e[q], bias, m, n + q, img);
+        for (int z = 1; z < KS; ++z)
+            if (z < p.ksplit) { v.x += part[z].x; v.y += part[z].y; v.z += part[z].z; v.w += part[z].w; }
+        for (int z = KS; z < p.ksplit; ++z) {
+            const float4 o = *reinterpret_cast<const float4*>(p.partial + (size_t)z * slab + idx);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (!second) {
+            if (p.res) { v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w; }
+            v = activate(p.act, v);
+            if (p.tbias) { v.x += tb.x; v.y += tb.y; v.z += tb.z; v.w += tb.w; }
+        }
+        *reinterpret_cast<float4*>((second ? p.out2 : p.out) + ro + col_offset(p, second ? n - p.n_split : n)) = v;
     }
 }
 
@@ -1124,6 +1286,7 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
                       (!a.res || a.ldr % 4 == 0) && (!a.tbias || a.tb_stride % 4 == 0);
     if (!vec4) return hipErrorInvalidValue;  // the epilogues store 16 bytes at a time
     if (a.a_mode == A_CONV && !a.zeros) return hipErrorInvalidValue;
+    if ((long long)a.M * a.N >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element indices within an output or slab
     if (a.out2 && (a.n_split <= 0 || a.n_split % BN || a.n_split >= a.N || a.st_mode != ST_ROW)) return hipErrorInvalidValue;
     if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
         a.M >= 32768 && !a.tbias && !a.res && !a.out2) {
@@ -1165,6 +1328,8 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
     // counts) must be multiples of that
     const bool half = igemm_uses_split(a);
     if (kw == 4 && (a.K % 64 || (ks > 1 && a.chunks_per_split % 2))) kw = 2;
+    if (kw == 12 && !half) kw = 4;
+    if (kw == 4 && half && bm == 64 && !a.force_kw) kw = 12;  // 16 waves that all stage and multiply -> 8 staging + 4 multiplying waves
 #define DANRA_LAUNCH_IGEMM(BM_, KW_, H_)                                                                  \
     do {                                                                                                  \
         dim3 grid((a.M + BM_ - 1) / BM_, a.N / BN, ks);                                                   \
@@ -1174,7 +1339,13 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
         else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
         else if (!H_) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1, false>), grid, dim3(256 * KW_), 0, stream, a); \
     } while (0)
-    if (half) {
+    if (half && kw == 12 && bm == 64) {  // wave roles: 4 multiplying + 8 staging waves
+        dim3 grid((a.M + 63) / 64, a.N / BN, ks);
+        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<64, 4, A_GEMM_LN, true, true>), grid, dim3(768), 0, stream, a);
+        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<64, 4, A_GEMM, true, true>), grid, dim3(768), 0, stream, a);
+        else if (a.nmean) hipLaunchKernelGGL((k_igemm<64, 4, A_CONV_IN, true, true>), grid, dim3(768), 0, stream, a);
+        else hipLaunchKernelGGL((k_igemm<64, 4, A_CONV, true, true>), grid, dim3(768), 0, stream, a);
+    } else if (half) {
         if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1, true);
         else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4, true);
         else if (kw == 2) DANRA_LAUNCH_IGEMM(64, 2, true);

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     };
     struct Cfg { int bm, kw, ks; };
     std::vector<Cfg> cfgs = {{0, 0, 1}, {128, 1, 1}, {64, 1, 1}, {64, 2, 1}, {64, 4, 1}, {64, 4, 2}, {64, 4, 4}, {64, 4, 8},
-                             {64, 2, 2}, {64, 2, 4}, {64, 1, 4}, {128, 1, 2}, {128, 1, 4}};
+                             {64, 2, 2}, {64, 2, 4}, {64, 1, 4}, {128, 1, 2}, {128, 1, 4}, {64, 12, 1}, {64, 12, 2}, {64, 12, 4}};
     const size_t big = (size_t)B * 64 * 64 * 64 + (1 << 20);
     float *A, *W, *out, *res, *bias, *partial;
     CK(hipMalloc(&A, big * 4));
@@ -109,7 +109,8 @@ int main(int argc, char** argv) {
             const Cfg& c = cfgs[ci];
             const int chunks = a.K / 32;
             if (c.ks > 1 && (chunks / c.ks < 4 || (size_t)c.ks * a.M * a.N > ((size_t)16 << 20))) continue;
-            if (c.kw == 4 && a.K % 64) continue;
+            if (c.kw >= 4 && a.K % 64) continue;
+            if (c.kw == 12 && !getenv("DANRA_TUNE_HALF")) continue;
             a.force_bm = c.bm; a.force_kw = c.kw; a.debug = debug;
             a.half = getenv("DANRA_TUNE_HALF") ? atoi(getenv("DANRA_TUNE_HALF")) : 0;
             a.ksplit = c.ks;
@@ -142,6 +143,30 @@ int main(int argc, char** argv) {
                 printf("   max |half - fp32| = %.3e of max |out| = %.3e (%.2e)", err, mx, err / mx);
             }
             printf("\n");
+            if (debug & 64) {  // clock readings of workgroup 0: per wave, mean cycles between the four stamps of an iteration
+                const int waves = c.kw == 12 ? 12 : 4 * c.kw;
+                std::vector<unsigned long long> ts((size_t)waves * 64 * 4);
+                CK(hipMemcpy(ts.data(), partial, ts.size() * 8, hipMemcpyDeviceToHost));
+                {
+                    std::vector<unsigned long long> ph(16 * 8);
+                    CK(hipMemcpy(ph.data(), (char*)partial + (size_t)16 * 64 * 4 * 8, ph.size() * 8, hipMemcpyDeviceToHost));
+                    for (int w = 0; w < waves; w += (waves > 4 ? 4 : 1))
+                        printf("      wave %2d phases: entry->pipeline %6llu  fill %6llu  loop %7llu  vote+reduce %6llu  epilogue %6llu ticks\n", w,
+                               ph[w * 8 + 1] - ph[w * 8], ph[w * 8 + 2] - ph[w * 8 + 1], ph[w * 8 + 3] - ph[w * 8 + 2], ph[w * 8 + 4] - ph[w * 8 + 3],
+                               ph[w * 8 + 5] - ph[w * 8 + 4]);
+                }
+                const int n_it = std::min(64, a.K / 64);
+                for (int w = 0; w < waves; ++w) {
+                    double d01 = 0, d12 = 0, d23 = 0, d30 = 0;
+                    for (int it = 2; it + 1 < n_it; ++it) {
+                        const unsigned long long* q = &ts[((size_t)w * 64 + it) * 4];
+                        d01 += (double)(q[1] - q[0]); d12 += (double)(q[2] - q[1]); d23 += (double)(q[3] - q[2]); d30 += (double)(q[4] - q[3]);
+                    }
+                    const int n = n_it - 3;
+                    printf("      wave %2d: s0->s1 %7.1f  s1->s2 %7.1f  s2->s3 %7.1f  s3->next s0 %7.1f   (iteration %7.1f ticks)\n", w, d01 / n, d12 / n,
+                           d23 / n, d30 / n, (d01 + d12 + d23 + d30) / n);
+                }
+            }
         }
     }
     return 0;

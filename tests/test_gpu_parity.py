@@ -376,6 +376,65 @@ def test_slices_of_a_batch_draw_the_noise_of_the_whole_batch(cond64, dev):
     assert torch.equal(run(0, 2, 0), run(0, 2, 0))  # the offset is per call: a later plain call is unchanged
 
 
+def conv2_reference(sd, x):
+    """Encoder.conv2 + bn1 (eval) + ReLU in float64 on the CPU (reference modules:186-191, 269-273)."""
+    d = {k: v.double() for k, v in sd.items() if k.startswith("encoder.conv2") or k.startswith("encoder.bn1")}
+    y = torch.nn.functional.conv2d(x.double(), d["encoder.conv2.weight"], stride=2, padding=3)
+    y = torch.nn.functional.batch_norm(y, d["encoder.bn1.running_mean"], d["encoder.bn1.running_var"],
+                                       d["encoder.bn1.weight"], d["encoder.bn1.bias"], training=False, eps=1e-5)
+    return torch.relu(y)
+
+
+@pytest.mark.parametrize("case", ["plain", "huge_value", "non_finite_free_huge_region", "tiny", "tiny_with_zeros", "zeros"])
+def test_split_operand_convolution_value_ranges(cond64, dev, case):
+    """The convolutions multiply on the fp16 matrix cores with both operands split in two fp16 halves while a
+    workgroup's staged activations stay below 2^15 and are not uniformly tiny; a workgroup that meets anything else
+    multiplies its 64 output rows again with fp32 instructions.  Every case stays within the per-op tolerance of a
+    float64 evaluation, judged per image region so that a huge value does not hide the error elsewhere."""
+    _, sd, ops = cond64
+    x = gs.randn(41, 2, 64, 32, 32)
+    if case == "huge_value":
+        x[0, 5, 10, 12] = 3.0e6
+    elif case == "non_finite_free_huge_region":
+        x[1, :, 16:, :] *= 1.0e5
+    elif case == "tiny":
+        x *= 1.0e-6
+    elif case == "tiny_with_zeros":
+        x *= 1.0e-5
+        x[:, :, ::2] = 0.0
+    elif case == "zeros":
+        x[0] = 0.0
+    want = conv2_reference(sd, x)
+    got = ops.conv2_bn_relu(x.to(dev)).cpu().double()
+    assert torch.isfinite(got).all()
+    # regions of comparable magnitude: each image's top and bottom half of the 16x16 output
+    for b in range(2):
+        for rows in (slice(0, 8), slice(8, 16)):
+            w, g = want[b, :, rows], got[b, :, rows]
+            scale = max(float(w.abs().max()), 1e-30)
+            assert float((g - w).abs().max()) <= TOL_OP * scale, (case, b, rows)
+
+
+def test_split_operand_forward_equals_fp32_products(cond64, golden, dev):
+    """danra_set_fp32_products(1) runs every product of the network with fp32 matrix instructions; both forms meet the
+    forward tolerance against the reference's own output and agree with each other far inside it."""
+    model, _, ops = cond64
+    want = torch.from_numpy(golden("forward64")["cond_t500"])
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 2, 64).items()}
+    t = torch.full((2,), 500, dtype=torch.long, device=dev)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            ops.lib.danra_set_fp32_products(mode)
+            with torch.no_grad():
+                outs[mode] = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
+    finally:
+        ops.lib.danra_set_fp32_products(0)
+    assert rel_err(outs[0], want) < TOL_FWD and rel_err(outs[1], want) < TOL_FWD
+    assert rel_err(outs[0], outs[1]) < 2e-5
+    assert not torch.equal(outs[0], outs[1]), "the switch changed nothing: the split-operand form did not run"
+
+
 def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
     """B = 33 at 64x64 puts 33792 tokens through the K=64 row-stationary GEMM (QKV at L=1024, final transposed
     convolution) with a partly empty last workgroup; every image must equal its own B = 1 evaluation."""
