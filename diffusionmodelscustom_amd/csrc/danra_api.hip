@@ -144,6 +144,7 @@ struct danra_handle_s {
     double prof_flops = 0.0;
     double prof_exec_flops = 0.0;   // multiply-adds the instructions executed (x2), see igemm()
     double prof_split_flops = 0.0;  // the part of prof_flops that ran in the split-operand fp16 form
+    double prof_bytes = 0.0;        // operands, weights and results of the timed launches, each counted once
     // sampling loop: 1 = replay one captured denoise step (hipGraph), 0 = enqueue every kernel
     int graph_mode = 1;
     hipStream_t cap_stream = nullptr;
@@ -659,30 +660,55 @@ int run_stem(danra_handle_s* h, const float* const planes[4], float* out, int B,
     return DANRA_OK;
 }
 
-int prof_mark(danra_handle_s* h, hipStream_t st) {
-    if (h->prof_used == h->prof_events.size()) {
+// Hands the next two profiling events to a launch (LaunchEvents::take): the pair is attached to the dispatch and
+// carries the kernel's begin and end times.
+int prof_take(void* ctx, hipEvent_t* start, hipEvent_t* stop) {
+    danra_handle_s* h = static_cast<danra_handle_s*>(ctx);
+    while (h->prof_events.size() < h->prof_used + 2) {
         hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
+        if (hipEventCreate(&e) != hipSuccess) return 1;  // (the launch then goes untimed)
         h->prof_events.push_back(e);
     }
-    HIP_TRY(hipEventRecord(h->prof_events[h->prof_used++], st));
-    return DANRA_OK;
+    *start = h->prof_events[h->prof_used];
+    *stop = h->prof_events[h->prof_used + 1];
+    h->prof_used += 2;
+    return 0;
 }
 
+// Scope in which the launches of this thread are timed for handle `h`.
+struct ProfScope {
+    LaunchEvents src;
+    bool on;
+    ProfScope(danra_handle_s* h, bool enable) : src{h, prof_take}, on(enable) {
+        if (on) t_launch_events = &src;
+    }
+    ~ProfScope() {
+        if (on) t_launch_events = nullptr;
+    }
+};
+
 // Every implicit GEMM of the forward schedule goes through here: with the family being timed (danra_profile_begin),
-// the launch - its split-K reduction kernel included - is bracketed by events.
+// each of its kernels - the split-K reduction kernel is one - carries its own pair of events.
 int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
     const bool timed = h->prof_kind == DANRA_PROF_IGEMM && h->prof_now;
-    if (timed) RC_TRY(prof_mark(h, st));
-    HIP_TRY(launch_igemm(a, st));
+    {
+        ProfScope scope(h, timed);
+        HIP_TRY(launch_igemm(a, st));
+    }
     if (timed) {
-        RC_TRY(prof_mark(h, st));
         const double fl = 2.0 * (double)a.M * (double)a.N * (double)a.K;
         h->prof_flops += fl;
         // the split-operand form issues three fp16 products per algorithmic one
         const bool split = igemm_uses_split(a);
         h->prof_exec_flops += split ? 3.0 * fl : fl;
         if (split) h->prof_split_flops += fl;
+        // one pass over the input tensor (a convolution reads every input element, however many windows hold it),
+        // the weights, the result and what the epilogue adds to it
+        double elems = (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2.0 : 1.0);
+        if (a.a_mode == A_GEMM) elems += (double)a.M * a.K;
+        else if (a.a_mode == A_CONV) elems += (double)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi * a.Cin;
+        else elems += (double)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi * (a.K / 64);  // stem: K = planes x 8 x 8
+        h->prof_bytes += 4.0 * elems;
     }
     return DANRA_OK;
 }
@@ -707,13 +733,15 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     const size_t plane = (size_t)B * L * C;
     const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
     const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
-    if (timed) RC_TRY(prof_mark(h, st));
-    HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+    {
+        ProfScope scope(h, timed);
+        HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+    }
     if (timed) {
-        RC_TRY(prof_mark(h, st));
         const double fl = 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
         h->prof_flops += fl;
         h->prof_exec_flops += (hd == 16 && L % 128 == 0) ? 3.5 * fl : fl;  // head_dim 16: 4 + 3 fp16 instructions per 2 algorithmic products
+        h->prof_bytes += 4.0 * 4.0 * (double)plane;  // q, k, v read once, the head outputs written once
     }
     // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
     // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
@@ -1338,6 +1366,7 @@ int danra_profile_begin(danra_handle_t h, int kind) {
     h->prof_flops = 0.0;
     h->prof_exec_flops = 0.0;
     h->prof_split_flops = 0.0;
+    h->prof_bytes = 0.0;
     return DANRA_OK;
 }
 
@@ -1363,6 +1392,12 @@ int danra_profile_executed(danra_handle_t h, double* executed_flops, double* spl
     if (!h) return fail(DANRA_EINVAL, "null handle");
     if (executed_flops) *executed_flops = h->prof_exec_flops;
     if (split_flops) *split_flops = h->prof_split_flops;
+    return DANRA_OK;
+}
+
+int danra_profile_bytes(danra_handle_t h, double* algorithmic_bytes) {
+    if (!h) return fail(DANRA_EINVAL, "null handle");
+    if (algorithmic_bytes) *algorithmic_bytes = h->prof_bytes;
     return DANRA_OK;
 }
 

@@ -2,10 +2,32 @@
 // Every launcher enqueues on `stream` and returns immediately; shapes are validated by the caller.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
 namespace danra {
+
+// Timing hook for the kernel families that can be profiled from the C ABI.  While a source is set (per host thread),
+// every launch through DANRA_LAUNCH_KERNEL takes an event pair from it and attaches the pair to the dispatch itself
+// (hipExtLaunchKernelGGL): the events then carry the kernel's own begin and end times, what a kernel trace reports
+// as its duration.  Events recorded around a launch would add the two marker packets and the launch latency, 5-7 us
+// on kernels that run for 10.
+struct LaunchEvents {
+    void* ctx;
+    int (*take)(void* ctx, hipEvent_t* start, hipEvent_t* stop);  // 0 = a pair was handed out
+};
+extern thread_local const LaunchEvents* t_launch_events;  // (kernels_misc.hip)
+
+#define DANRA_LAUNCH_KERNEL(kernel, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                              \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                                    \
+        const ::danra::LaunchEvents* src_ = ::danra::t_launch_events;                                                 \
+        if (src_ && src_->take(src_->ctx, &ev0_, &ev1_) == 0)                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev0_, ev1_, 0, __VA_ARGS__);                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                        \
+    } while (0)
 
 // ---------------------------------------------------------------- implicit GEMM (convs, linears)
 enum AMode { A_GEMM = 0, A_CONV = 1, A_CONV1 = 2 };

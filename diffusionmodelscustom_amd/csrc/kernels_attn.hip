@@ -576,7 +576,7 @@ static hipError_t launch_flash_wide_qt(const float* q, const float* k, const flo
         if (e != hipSuccess) return e;
     }
     const float scale_log2e = (1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
-    hipLaunchKernelGGL((k_flash_wide<DT, QT>), dim3((L / (64 * QT)) * B * heads), dim3(256), lds, stream, q, k, v, out, L,
+    DANRA_LAUNCH_KERNEL((k_flash_wide<DT, QT>), dim3((L / (64 * QT)) * B * heads), dim3(256), lds, stream, q, k, v, out, L,
                        heads, B * heads, scale_log2e);
     return hipGetLastError();
 }
@@ -879,10 +879,10 @@ hipError_t launch_attention_hd16(const float* q, const float* k, const float* v,
     const float scale_log2e = 0.25f * 1.4426950408889634f;
     dim3 grid((L / 128) * B * heads);
     if (g_hd16_fp32_products)
-        hipLaunchKernelGGL((k_flash_hd16<2, 0, false, false>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads,
+        DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, false, false>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads,
                            B * heads, scale_log2e);
     else
-        hipLaunchKernelGGL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
+        DANRA_LAUNCH_KERNEL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
     return hipGetLastError();
 }
 

@@ -1308,7 +1308,7 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             if (e != hipSuccess) return e;                                                                  \
         }                                                                                                   \
-        hipLaunchKernelGGL(k_gemm_k64<NW4_>, grid, block, lds, stream, b);                                  \
+        DANRA_LAUNCH_KERNEL(k_gemm_k64<NW4_>, grid, block, lds, stream, b);                                  \
     } while (0)
         if (nw4 <= 4) DANRA_LAUNCH_K64(4);
         else DANRA_LAUNCH_K64(16);
@@ -1333,18 +1333,18 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
 #define DANRA_LAUNCH_IGEMM(BM_, KW_, H_)                                                                  \
     do {                                                                                                  \
         dim3 grid((a.M + BM_ - 1) / BM_, a.N / BN, ks);                                                   \
-        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM_LN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
-        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_GEMM, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
-        else if (a.a_mode == A_CONV && a.nmean) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV_IN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
-        else if (a.a_mode == A_CONV) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
-        else if (!H_) hipLaunchKernelGGL((k_igemm<BM_, KW_, A_CONV1, false>), grid, dim3(256 * KW_), 0, stream, a); \
+        if (a.a_mode == A_GEMM && a.ln) DANRA_LAUNCH_KERNEL((k_igemm<BM_, KW_, A_GEMM_LN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
+        else if (a.a_mode == A_GEMM) DANRA_LAUNCH_KERNEL((k_igemm<BM_, KW_, A_GEMM, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else if (a.a_mode == A_CONV && a.nmean) DANRA_LAUNCH_KERNEL((k_igemm<BM_, KW_, A_CONV_IN, H_>), grid, dim3(256 * KW_), 0, stream, a); \
+        else if (a.a_mode == A_CONV) DANRA_LAUNCH_KERNEL((k_igemm<BM_, KW_, A_CONV, H_>), grid, dim3(256 * KW_), 0, stream, a);   \
+        else if (!H_) DANRA_LAUNCH_KERNEL((k_igemm<BM_, KW_, A_CONV1, false>), grid, dim3(256 * KW_), 0, stream, a); \
     } while (0)
     if (half && kw == 12 && bm == 64) {  // wave roles: 4 multiplying + 8 staging waves
         dim3 grid((a.M + 63) / 64, a.N / BN, ks);
-        if (a.a_mode == A_GEMM && a.ln) hipLaunchKernelGGL((k_igemm<64, 4, A_GEMM_LN, true, true>), grid, dim3(768), 0, stream, a);
-        else if (a.a_mode == A_GEMM) hipLaunchKernelGGL((k_igemm<64, 4, A_GEMM, true, true>), grid, dim3(768), 0, stream, a);
-        else if (a.nmean) hipLaunchKernelGGL((k_igemm<64, 4, A_CONV_IN, true, true>), grid, dim3(768), 0, stream, a);
-        else hipLaunchKernelGGL((k_igemm<64, 4, A_CONV, true, true>), grid, dim3(768), 0, stream, a);
+        if (a.a_mode == A_GEMM && a.ln) DANRA_LAUNCH_KERNEL((k_igemm<64, 4, A_GEMM_LN, true, true>), grid, dim3(768), 0, stream, a);
+        else if (a.a_mode == A_GEMM) DANRA_LAUNCH_KERNEL((k_igemm<64, 4, A_GEMM, true, true>), grid, dim3(768), 0, stream, a);
+        else if (a.nmean) DANRA_LAUNCH_KERNEL((k_igemm<64, 4, A_CONV_IN, true, true>), grid, dim3(768), 0, stream, a);
+        else DANRA_LAUNCH_KERNEL((k_igemm<64, 4, A_CONV, true, true>), grid, dim3(768), 0, stream, a);
     } else if (half) {
         if (bm == 128) DANRA_LAUNCH_IGEMM(128, 1, true);
         else if (kw == 4) DANRA_LAUNCH_IGEMM(64, 4, true);
@@ -1361,7 +1361,7 @@ hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, a);
+        DANRA_LAUNCH_KERNEL(k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, a);
         e = hipGetLastError();
     }
     return e;

@@ -5,6 +5,9 @@
 
 namespace danra {
 
+thread_local const LaunchEvents* t_launch_events = nullptr;
+
+
 // ------------------------------------------------------------------------------------------------
 // Time embeddings and the nine Sequential(SiLU, Linear(dim, C)) projections:
 // tbias[b][row] = W[row] . SiLU(emb(b)) + bias[row], emb = encoder embedding (+ label embedding) for

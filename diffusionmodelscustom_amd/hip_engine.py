@@ -75,6 +75,7 @@ _SIGNATURES = {
     "danra_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                          ctypes.POINTER(ctypes.c_double)]),
     "danra_profile_executed": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "danra_profile_bytes": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
     "danra_tbias_width": (ctypes.c_int, [_P]),
     "danra_time_embed": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
     "danra_attention": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
@@ -428,6 +429,13 @@ class UNetEngine:
         _check(self.lib, self.lib.danra_profile_executed(self.handle, ctypes.byref(ex), ctypes.byref(sp)),
                "danra_profile_executed")
         return ex.value, sp.value
+
+    def profile_bytes(self):
+        """Algorithmic bytes (every operand, weight and result once, 4 bytes an element) of the launches counted by the last
+        profile_begin / profile_end pair."""
+        b = ctypes.c_double()
+        _check(self.lib, self.lib.danra_profile_bytes(self.handle, ctypes.byref(b)), "danra_profile_bytes")
+        return b.value
 
     # ------------------------------------------------------------------ hot path
     def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):

@@ -226,6 +226,10 @@ int danra_profile_end(danra_handle_t h, double* total_ms, long long* launches, d
  * split-operand launch executes three fp16 products per algorithmic fp32 one, the head_dim-16 attention core 3.5) and
  * the algorithmic FLOPs that ran in the split-operand form.  Either pointer may be NULL. */
 int danra_profile_executed(danra_handle_t h, double* executed_flops, double* split_flops);
+/* Valid after danra_profile_end: the algorithmic bytes of the timed launches - every operand, weight and result of a
+ * launch counted once at 4 bytes per element (what a launch must move if nothing were cached across launches and
+ * nothing re-read within one). */
+int danra_profile_bytes(danra_handle_t h, double* algorithmic_bytes);
 
 /* ---- per-op entry points (unit parity tests of the kernels; NHWC = [B][H][W][C] fp32) ---- */
 

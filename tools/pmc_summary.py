@@ -1,7 +1,7 @@
-"""Summarise the two counter passes of tools/pmc_traffic.sh into the table kept as profiles/r01_pmc_traffic.txt and the
-flash-attention rows kept as profiles/r01_flash_traffic.json.
+"""Summarise the two counter passes of tools/pmc_traffic.sh into the table kept as profiles/r02_pmc_traffic.txt and the
+per-family averages that bench.py quotes as roofline.traffic, kept as profiles/r02_family_traffic.json.
 
-    python tools/pmc_summary.py gpurun_out/pmc > profiles/r01_pmc_traffic.txt
+    python tools/pmc_summary.py gpurun_out/pmc profiles/r02_family_traffic.json > profiles/r02_pmc_traffic.txt
 
 Counter unit: KiB.  gfx950 correction: FETCH_SIZE counts a 128-byte read request as 64 bytes, so reads = 2 x FETCH_SIZE;
 WRITE_SIZE is exact.  Median over the launches of each (kernel, grid size)."""
@@ -43,10 +43,25 @@ def main():
         print(f"{k[0]:34s} {k[1]:12d} {len(fetch[k]):8d} {f:15.1f} {w:15.1f} {2 * f / 1024:9.2f} {w / 1024:9.2f}")
         if k[0].startswith("k_flash_hd16"):
             flash[k[1]] = {"read_bytes": 2 * f * 1024, "write_bytes": w * 1024}
-    if len(sys.argv) > 2 and flash:
-        grids = sorted(flash, reverse=True)  # larger grid = L 1024, smaller = L 256 (batch 64, 4 heads)
-        out = {"k_flash_hd16": {"L1024_B64": flash[grids[0]], "L256_B64": flash[grids[-1]]},
-               "source": "tools/pmc_traffic.sh + tools/pmc_summary.py (FETCH_SIZE x2 on gfx950, WRITE_SIZE)"}
+    if len(sys.argv) > 2:
+        # per kernel family, as bench.py's roofline object averages it: HBM bytes over all launches / launches
+        families = {"igemm": ("k_igemm", "k_gemm_k64", "k_splitk_epilogue"), "flash": ("k_flash_hd16", "k_flash_wide")}
+        out = {}
+        for fam, prefixes in families.items():
+            total, launches = 0.0, 0
+            for k in fetch:
+                if not k[0].startswith(prefixes):
+                    continue
+                wr = write.get(k, [])
+                total += 1024.0 * (2.0 * sum(fetch[k]) + sum(wr))
+                launches += len(fetch[k])
+            if launches:
+                out[fam] = {"bytes_per_launch": total / launches, "launches_counted": launches,
+                            "source": "tools/pmc_traffic.sh + tools/pmc_summary.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, "
+                                      "mean over the family's launches of 11 denoise steps at batch 64"}
+        if flash:
+            grids = sorted(flash, reverse=True)  # larger grid = L 1024, smaller = L 256 (batch 64, 4 heads)
+            out["k_flash_hd16"] = {"L1024_B64": flash[grids[0]], "L256_B64": flash[grids[-1]]}
         with open(sys.argv[2], "w") as fh:
             json.dump(out, fh, indent=1)
 
