@@ -72,6 +72,9 @@ struct IGemmArgs {
     int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
     int keep_slabs;                // split-K only: leave the slabs in `partial` (no reduction kernel); the consumer sums them
     int half;                      // != 0: multiply on the fp16 matrix cores with operands split in two fp16 halves (k_igemm HALF)
+    // filled in by launch_igemm: log2 of a divisor of the row decomposition when it is a power of two, else -1
+    // (rows_per_img, batch, Ho*Wo, Wo, qkv_L, ct_H*ct_W, ct_W): the kernels then shift instead of dividing
+    int sh_rpi, sh_batch, sh_howo, sh_wo, sh_qkv_l, sh_ct_hw, sh_ct_w;
     int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);

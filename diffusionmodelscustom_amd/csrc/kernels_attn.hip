@@ -14,6 +14,8 @@
 // k_flash_wide: the flash scheme for head_dim 32 / 64 and L a multiple of 128 (networks with 2 heads or 1 head).
 //
 // k_attn_small: fallback for any other shape (plain VALU, keys walked in LDS chunks with online softmax).
+#include <type_traits>
+
 #include "danra_kernels.h"
 #include "split_f16.h"
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
     __shared__ __attribute__((aligned(16))) _Float16 Kh[QKH ? 2 : 1][QKH ? KVT * KHROW : 8];
     __shared__ int vbig_s;
-    static_assert(PVH || !QKH, "the fp16 QK^T product shares the range flag of the fp16 PV product");
+    static_assert(PVH == QKH, "both products run on the fp16 matrix cores, or neither");
     constexpr float RESCALE = PVH ? 15.f : RESCALE_LOG2;  // log2 of the largest probability relative to the reference
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group).  The linear id is
@@ -155,48 +157,64 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         lrun[t] = f32x2{0.f, 0.f};
     }
 
-    // staging: 64 keys x 16 floats = 256 float4 per operand, one per thread
+    // staging: 64 keys x 16 floats per operand.  K (and both operands of the all-fp32 form): one float4 per thread,
+    // key srow, columns sc4 .. sc4 + 3.  V of the fp16 form: four floats per thread, ONE column vd of the four keys
+    // that are neighbours in a lane's slot order (16 vj + 4 vg + r of half vhalf, r = 0..3: see Vh), so that their
+    // halves leave as two 8-byte LDS writes (lanes l, l+1, .. walk vg then vd: conflict-free) instead of eight 2-byte
+    // ones that collide four ways.
     const int srow = tid >> 2, sc4 = (tid & 3) * 4;
+    const int vd = lane >> 2, vg = lane & 3, vj = wave & 1, vhalf = wave >> 1;
+    const int vkey = 32 * vhalf + 16 * vj + 4 * vg;  // first of this thread's four keys within a tile
     float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
-    float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * 16 + sc4);
-    // this thread's key within its 32-key half: slot 4j + r of k-group g (see Vh)
-    const int vh_half = srow >> 5, vh_off = ((srow >> 2) & 3) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
+    float4 vreg;
+    auto load_v = [&](int tile) {
+        if (PVH) {
+            const float* vp = Vb + (size_t)(tile * KVT + vkey) * 16 + vd;
+            vreg = make_float4(vp[0], vp[16], vp[32], vp[48]);
+        } else {
+            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * KVT + srow) * 16 + sc4);
+        }
+    };
+    load_v(0);
+    // x = h + 2^-11 l: h = fp16(x) rounded towards zero, l = fp16(2^11 (x - h)) (the difference is exact in fp32);
+    // five instructions per pair of values
+    auto split_scaled = [&](float x0, float x1, unsigned& h, unsigned& l) {
+        typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+        h = __builtin_bit_cast(unsigned, (fp16x2_t)__builtin_amdgcn_cvt_pkrtz(x0, x1));
+        const float m2048 = -2048.f, s0 = x0 * 2048.f, s1 = x1 * 2048.f;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(m2048), "v"(s0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(m2048), "v"(s1));
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto stage = [&](int buf) {
         if (F32_TILES) {
             *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
             *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
         }
         if (QKH) {
-            const float kk[4] = {kreg.x, kreg.y, kreg.z, kreg.w};
-            f16x4 h4, l4, s4;
-            bool bounded = true;
+            unsigned h[2], l[2], sh[2];
+            split_scaled(kreg.x, kreg.y, h[0], l[0]);
+            split_scaled(kreg.z, kreg.w, h[1], l[1]);
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 tiny2 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const _Float16 hi = (_Float16)kk[c];
-                h4[c] = hi;
-                l4[c] = (_Float16)((kk[c] - (float)hi) * 2048.f);
-                s4[c] = (_Float16)((float)hi * 0.00048828125f);
-                bounded = bounded && (fabsf(kk[c]) < 32768.f);
-            }
-            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + sc4]) = h4;
-            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + 16 + sc4]) = l4;
-            *reinterpret_cast<f16x4*>(&Kh[buf][srow * KHROW + 32 + sc4]) = s4;
-            if (!bounded) vbig_s = 1;
+            for (int c = 0; c < 2; ++c) sh[c] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, h[c]) * tiny2);  // 2^-11 h (v_pk_mul_f16)
+            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + sc4]) = u32x2{h[0], h[1]};
+            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 16 + sc4]) = u32x2{l[0], l[1]};
+            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 32 + sc4]) = u32x2{sh[0], sh[1]};
+            const float kmax = fmaxf(max3f(fabsf(kreg.x), fabsf(kreg.y), fabsf(kreg.z)), fabsf(kreg.w));
+            if (!(kmax < 32768.f)) vbig_s = 1;
         }
         if (PVH) {
-            const float vv[4] = {vreg.x, vreg.y, vreg.z, vreg.w};
-            bool bounded = true, tiny = true;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const _Float16 hi = (_Float16)vv[c];
-                const _Float16 lo = (_Float16)((vv[c] - (float)hi) * 2048.f);
-                Vh[buf][0][vh_half][(sc4 + c) * 32 + vh_off] = hi;
-                Vh[buf][1][vh_half][(sc4 + c) * 32 + vh_off] = lo;
-                bounded = bounded && (fabsf(vv[c]) < 32768.f);
-                tiny = tiny && (fabsf(vv[c]) < 0.0009765625f);
-            }
-            // never cleared: the tiles from this one on are multiplied in fp32
-            if (!bounded || __all(tiny)) vbig_s = 1;
+            unsigned h[2], l[2];
+            split_scaled(vreg.x, vreg.y, h[0], l[0]);
+            split_scaled(vreg.z, vreg.w, h[1], l[1]);
+            const int at = (vd * 4 + vg) * 8 + 4 * vj;
+            *reinterpret_cast<u32x2*>(&Vh[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
+            *reinterpret_cast<u32x2*>(&Vh[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
+            const float vmax = fmaxf(max3f(fabsf(vreg.x), fabsf(vreg.y), fabsf(vreg.z)), fabsf(vreg.w));
+            // (a wave stages 16 keys x 16 columns.)  Never cleared: the tiles from this one on are multiplied in fp32
+            if (!(vmax < 32768.f) || __all(vmax < 0.0009765625f)) vbig_s = 1;
         }
     };
     if (PVH) {
@@ -219,17 +237,21 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
             kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
-            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * KVT + srow) * 16 + sc4);
+            load_v(nxt);
         }
         // The 64-key tile is consumed in two halves of 32 keys (QK^T -> softmax -> PV each), which keeps
-        // the live score registers at 8 per query tile.
+        // the live score registers at 8 per query tile.  `fast`: both products on the fp16 matrix cores; decided once
+        // per tile, so that the body is one long basic block in which the compiler can interleave the matrix
+        // instructions of one query tile with the softmax arithmetic of the other.
+        auto tile_body = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 32hf + 16j + 4g + r) - reference
             f32x4 s[QT][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (QKH && !vbig) {
+                if (QKH && FAST) {
                     const _Float16* krow = &Kh[buf][((2 * hf + j) * 16 + lq) * KHROW + 8 * g];
                     const f16x8 ka1 = *reinterpret_cast<const f16x8*>(krow);
                     const f16x8 ka2 = *reinterpret_cast<const f16x8*>(krow + 32);
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 }
             }
             // ---- O^T += V^T P^T : A = V^T, B = P (the S^T registers)
-            if (PVH && !vbig) {  // fp16 halves, 32 keys per product: lane (d, g) holds V[key 16j + 4g + r][d] in slot 4j + r
+            if (PVH && FAST) {  // fp16 halves, 32 keys per product: lane (d, g) holds V[key 16j + 4g + r][d] in slot 4j + r
                 const f16x8 vhi = *reinterpret_cast<const f16x8*>(&Vh[buf][0][hf][(lq * 4 + g) * 8]);
                 const f16x8 vlo = *reinterpret_cast<const f16x8*>(&Vh[buf][1][hf][(lq * 4 + g) * 8]);
 #pragma unroll
@@ -350,6 +372,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     }
             }
         }
+        };
+        if (PVH && !vbig) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
         if (!(ABL & 4)) {
             stage(buf ^ 1);
             __syncthreads();

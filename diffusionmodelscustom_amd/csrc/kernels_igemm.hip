@@ -37,19 +37,24 @@ __device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
 
 static constexpr int BN = 64;
 
+// x / d for x >= 0, d > 0: a shift when the host found d to be a power of two (sh = its log2, else -1).  Every
+// feature map of the networks this library runs has power-of-two sides; an integer division by a run-time value
+// costs some forty instructions, and the set-up of a workgroup does a dozen of them before its first load.
+__device__ __forceinline__ int div_by(int x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
+
 // Output address = row part (depends on m) + column part (depends on n), for every store mode.
 __device__ __forceinline__ unsigned long long row_offset(const IGemmArgs& p, int m, int& img) {
-    img = m / p.rows_per_img;
+    img = div_by(m, p.rows_per_img, p.sh_rpi);
     if (p.st_mode == ST_ROW) return (unsigned long long)m * p.ldc;
     if (p.st_mode == ST_QKV) {
-        const int b = m / p.qkv_L;
+        const int b = div_by(m, p.qkv_L, p.sh_qkv_l);
         const int l = m - b * p.qkv_L;
         return ((unsigned long long)b * p.qkv_L * p.qkv_C) + (unsigned long long)l * p.qkv_hd;
     }
     const int hw = p.ct_H * p.ct_W;  // ST_CONVT: m = (b, y, x) of the input grid
-    const int b = m / hw;
+    const int b = div_by(m, hw, p.sh_ct_hw);
     const int r = m - b * hw;
-    const int y = r / p.ct_W;
+    const int y = div_by(r, p.ct_W, p.sh_ct_w);
     const int x = r - y * p.ct_W;
     return (((unsigned long long)b * 2 * p.ct_H + 2 * y) * 2 * p.ct_W + 2 * x) * p.ct_C;
 }
@@ -59,7 +64,7 @@ __device__ __forceinline__ unsigned long long row_offset(const IGemmArgs& p, int
 // kernel taps that fall inside the image; everything else is image-major (identity).
 __device__ __forceinline__ int out_row(const IGemmArgs& p, int m) {
     if (!p.pix_major) return m;
-    const int r = m / p.batch;
+    const int r = div_by(m, p.batch, p.sh_batch);
     const int b = m - r * p.batch;
     return b * (p.Ho * p.Wo) + r;
 }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
         rowOut[tid] = mo;
         if (CONV && p.pix_major) {  // taps of this row that read inside the image: iy = oy*stride - pad + kh in [0, Hi)
             const int r = mo - img * (p.Ho * p.Wo);
-            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int oy = div_by(r, p.Wo, p.sh_wo), ox = r - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             int lo_h = max(0, -iy0), hi_h = min(p.KH - 1, p.Hi - 1 - iy0);
             int lo_w = max(0, -ix0), hi_w = min(p.KW - 1, p.Wi - 1 - ix0);
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
         nbase[j] = 0;
         if (!GEMM) {
             const int mo = out_row(p, rm[j]);
-            const int b = mo / howo;
+            const int b = div_by(mo, howo, p.sh_howo);
             const int r = mo - b * howo;
-            const int oy = r / p.Wo;
+            const int oy = div_by(r, p.Wo, p.sh_wo);
             const int ox = r - oy * p.Wo;
             rb[j] = b;
             riy[j] = oy * p.stride - p.pad;
@@ -300,6 +305,32 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
             for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o);
             rmean[j] = mean;
             rrstd[j] = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
+        }
+    }
+
+    // ---- what the epilogue adds to this thread's results.  With wave roles every thread has registers to spare and
+    // the kernels are short (a dozen chunks on the small maps): bias, residual and embedding bias are fetched now,
+    // which takes a trip to memory off the end of the kernel.
+    constexpr int ESWEEP = SPEC ? T / 16 : 16;  // output rows per sweep of the threads that take part in the epilogue
+    constexpr int NEJ = (BM + ESWEEP - 1) / ESWEEP;
+    const int oc4 = (tid & 15) * 4;
+    const int n = n0 + oc4;
+    // columns from n_split on belong to the second output (same rows, its own column 0, bias only); BN divides
+    // n_split, so a workgroup's columns lie on one side
+    const bool second = p.out2 && n0 >= p.n_split;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SPEC && p.bias && p.ksplit <= 1) bv = *reinterpret_cast<const float4*>(p.bias + n);
+    float4 pre_res[NEJ], pre_tb[NEJ];
+    if (SPEC && p.ksplit <= 1 && !second) {
+#pragma unroll
+        for (int j = 0; j < NEJ; ++j) {
+            const int row = (tid >> 4) + ESWEEP * j;
+            pre_res[j] = pre_tb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= BM || m0 + row >= p.M) continue;
+            const int mo = out_row(p, m0 + row);
+            if (p.res) pre_res[j] = *reinterpret_cast<const float4*>(p.res + (size_t)mo * p.ldr + n);
+            if (p.tbias)
+                pre_tb[j] = *reinterpret_cast<const float4*>(p.tbias + (size_t)div_by(mo, p.rows_per_img, p.sh_rpi) * p.tb_stride + n);
         }
     }
 
@@ -536,6 +567,18 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
         }
 #endif
     };
+    // Range check of the split (HALF): a staged value of 2^15 or more (or an infinity) does not fit the fp16 high half,
+    // and a tile whose largest value is below 2^-8 would be kept to an absolute 2^-25 only, i.e. to fewer than 17 bits
+    // (an all-zero tile is exact).  The staging waves cast their votes ahead of the last barrier of the loop - the last
+    // iteration stages nothing new, so `amax` is final by then - and everybody reads the result behind it.
+    auto vote = [&](int it) {
+        if (it != n_chunks - 1) return;
+        const bool too_big = !(amax < 32768.f);
+        const bool normal = amax >= 0.00390625f;
+        if (__any(too_big) && lane == 0) rangeFlag[0] = 1;
+        if (__any(normal) && lane == 0) rangeFlag[1] = 1;
+        if (__any(amax > 0.f) && lane == 0) rangeFlag[2] = 1;
+    };
     auto iteration = [&](auto h, auto set_tag, auto load_tag, int it, auto role) {
         constexpr int NKB = decltype(h)::value ? NKB16 : NKB32;
         constexpr int ROLE = decltype(role)::value;
@@ -543,6 +586,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
             // (loads issued ahead of the conversions and LDS writes, or by half of the staging waves only, took longer)
             stamp(it, 0);
             store_chunk(h, set_tag, (it + 1) & 1);
+            if (decltype(h)::value) vote(it);
             stamp(it, 1);
             load_chunk(load_tag);
             stamp(it, 2);
@@ -570,6 +614,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
         __builtin_amdgcn_sched_barrier(0);
         stamp(it, 1);
         if (!(dbg & 4)) store_chunk(h, set_tag, (it + 1) & 1);  // (in the last iteration a copy of the last chunk that nobody reads)
+        if (decltype(h)::value) vote(it);
         stamp(it, 2);
         if (!(dbg & 16)) load_chunk(load_tag);
         __builtin_amdgcn_sched_barrier(0);
@@ -620,16 +665,8 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
     auto product = [&](auto role) {
         pipeline(std::integral_constant<bool, HALF>{}, role);
         if (!HALF) return;
-        // Range check of the split: a staged value of 2^15 or more (or an infinity) does not fit the fp16 high half,
-        // and a tile whose largest value is below 2^-8 would be kept to an absolute 2^-25 only, i.e. to fewer than
-        // 17 bits (an all-zero tile is exact).  Either way the workgroup multiplies its tile again with fp32
-        // instructions, from the fp32 weights.  (A NaN comes out as a NaN in both forms.)
-        const bool too_big = !(amax < 32768.f);
-        const bool normal = amax >= 0.00390625f;
-        if (__any(too_big) && lane == 0) rangeFlag[0] = 1;
-        if (__any(normal) && lane == 0) rangeFlag[1] = 1;
-        if (__any(amax > 0.f) && lane == 0) rangeFlag[2] = 1;
-        __syncthreads();
+        // A failed range check (see `vote`): the workgroup multiplies its tile again with fp32 instructions, from the
+        // fp32 weights.  (A NaN comes out as a NaN in both forms.)
         const bool redo = rangeFlag[0] != 0 || (rangeFlag[2] != 0 && rangeFlag[1] == 0);
         if (__builtin_amdgcn_readfirstlane(redo ? 1 : 0)) {
 #pragma unroll
@@ -696,15 +733,8 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
                     make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
         __syncthreads();
     }
-    constexpr int ESWEEP = SPEC ? T / 16 : 16;  // output rows per sweep of the threads that are left
     phase_stamp(4);
-    const int oc4 = (tid & 15) * 4;
-    const int n = n0 + oc4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && p.ksplit <= 1) bv = *reinterpret_cast<const float4*>(p.bias + n);
-    // columns from n_split on belong to the second output (same rows, its own column 0, bias only); BN divides
-    // n_split, so a workgroup's columns lie on one side
-    const bool second = p.out2 && n0 >= p.n_split;
+    if (!SPEC && p.bias && p.ksplit <= 1) bv = *reinterpret_cast<const float4*>(p.bias + n);
     float* const outp = second ? p.out2 : p.out;
     const unsigned long long co = col_offset(p, second ? n - p.n_split : n);
 #pragma unroll
@@ -734,12 +764,12 @@ __global__ __launch_bounds__(SPEC ? 768 : 256 * KW) void k_igemm(const IGemmArgs
             continue;
         }
         if (p.res) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rowOut[row] * p.ldr + n);
+            const float4 rv = SPEC ? pre_res[j] : *reinterpret_cast<const float4*>(p.res + (size_t)rowOut[row] * p.ldr + n);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         v = activate(p.act, v);
         if (p.tbias) {
-            const float4 tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)rowImg[row] * p.tb_stride + n);
+            const float4 tv = SPEC ? pre_tb[j] : *reinterpret_cast<const float4*>(p.tbias + (size_t)rowImg[row] * p.tb_stride + n);
             v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
         }
         *reinterpret_cast<float4*>(outp + rowOff[row] + co) = v;
@@ -1279,7 +1309,22 @@ bool igemm_uses_split(const IGemmArgs& a) {
            (a.a_mode != A_CONV || a.Cin % 64 == 0) && (ks == 1 || a.chunks_per_split % 2 == 0);
 }
 
-hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream) {
+static int log2_if_pow2(long long d) {
+    if (d <= 0 || (d & (d - 1))) return -1;
+    int s = 0;
+    while ((1ll << s) < d) ++s;
+    return s;
+}
+
+hipError_t launch_igemm(const IGemmArgs& args, hipStream_t stream) {
+    IGemmArgs a = args;
+    a.sh_rpi = log2_if_pow2(a.rows_per_img);
+    a.sh_batch = log2_if_pow2(a.batch);
+    a.sh_howo = log2_if_pow2((long long)a.Ho * a.Wo);
+    a.sh_wo = log2_if_pow2(a.Wo);
+    a.sh_qkv_l = log2_if_pow2(a.qkv_L);
+    a.sh_ct_hw = log2_if_pow2((long long)a.ct_H * a.ct_W);
+    a.sh_ct_w = log2_if_pow2(a.ct_W);
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     // every store mode keeps runs of four output columns contiguous when its inner extent is a multiple of 4
     const bool vec4 = a.ldc % 4 == 0 && (a.st_mode != ST_QKV || a.qkv_hd % 4 == 0) && (a.st_mode != ST_CONVT || a.ct_C % 4 == 0) &&

@@ -14,18 +14,18 @@ using namespace danra;
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 
-template <int ABL, bool PVH = true, bool QKH = PVH>
+template <int ABL, bool PVH = true, bool QKH = PVH, int QT = 2>
 static void run(const char* name, const float* q, const float* k, const float* v, float* o, int B, int L) {
     const int heads = 4;
     const float sc = 0.25f * 1.4426950408889634f;
-    dim3 grid((L / 128) * B * heads);
+    dim3 grid((L / (64 * QT)) * B * heads);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e0, 0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<2, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -47,8 +47,9 @@ int main(int argc, char** argv) {
     hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
-    run<0, true, false>("full, only PV in fp16", q, k, v, o, B, L);
     run<0>("full", q, k, v, o, B, L);
+    run<0, true, true, 4>("full, 64 queries per wave", q, k, v, o, B, L);
+    run<0, true, true, 1>("full, 16 queries per wave", q, k, v, o, B, L);
     {   // the fp16-halves product against the all-fp32 product on the same data
         float* o2;
         hipMalloc(&o2, n * 4);

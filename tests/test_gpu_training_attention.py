@@ -222,7 +222,8 @@ def test_training_step_gradients(builder, monkeypatch):
     """One training step's loss and parameter gradients (train mode: batch statistics in BatchNorm) against a float64
     evaluation of the same step on the CPU, for three float32 evaluations on the GPU: the 64-channel attention cores in
     the native library with their default split-operand fp16 products, the same kernels with fp32 matrix instructions
-    only, and torch's own attention.  Bar: 5e-3 rms per tensor for each of them.
+    only, and torch's own attention.  Bars, per evaluation: the median over the parameter tensors of the rms gradient
+    error (relative to the tensor's rms) at most 2e-4, and no tensor further than 3e-2.
 
     Why eight images: the gradient of this piecewise-linear network is discontinuous wherever a ReLU input crosses
     zero, and of its few million ReLU inputs a handful always sit within float32 rounding of zero, so two correct float32
@@ -230,8 +231,11 @@ def test_training_step_gradients(builder, monkeypatch):
     encoder.layer1 moves the stem's weight gradient by 3.8e-3 of its rms - torch on the CPU and both native forms on one
     side, torch on the GPU and float64 on the other for one network, torch on the CPU alone on the other side for the
     other network - while evaluations on the same side agree to 5e-6.  A flip's share of a mean-squared-error gradient
-    falls with the number of images; at eight one flip stays near 1e-3, inside the bar, and the evaluations that meet no
-    flip agree with float64 to 2e-6."""
+    falls with the number of images; at eight one flip moves the tensors next to it by 1e-3 to 6e-3 (every one of the
+    three GPU evaluations has met one in some run, torch's own included) and leaves most tensors where they were, while
+    an evaluation that meets no flip agrees with float64 to 2e-6 in every tensor.  Hence the two bars: the median, which
+    a flip does not move and a loss of precision in a kernel would (operands rounded to plain fp16 are off by up to
+    5e-4 each), and a ceiling per tensor that a few flips stay under and a wrong kernel does not."""
     torch.manual_seed(11)
     model = builder()
     model.train()
@@ -259,7 +263,7 @@ def test_training_step_gradients(builder, monkeypatch):
         assert set(got) == set(want)
         rel = {n: (got[n] - want[n]).norm().item() / want[n].numel() ** 0.5 / max(rms[n], floor) for n in want}
         n = max(rel, key=rel.get)
-        return rel[n], n
+        return rel[n], n, sorted(rel.values())[len(rel) // 2]
 
     lib = hip_engine.load_library()
     gpu = copy.deepcopy(model).to(DEV)
@@ -280,11 +284,12 @@ def test_training_step_gradients(builder, monkeypatch):
     loss, grads = step(gpu, DEV)
     assert len(fwd) == 0, "the comparison step must not use the native core"
     report["torch attention on the GPU"] = (abs(loss - want_loss) / abs(want_loss),) + worst(grads)
-    text = "; ".join(f"{k}: loss {v[0]:.1e}, worst gradient {v[1]:.2e} ({v[2]})" for k, v in report.items())
+    text = "; ".join(f"{k}: loss {v[0]:.1e}, worst gradient {v[1]:.2e} ({v[2]}), median {v[3]:.1e}" for k, v in report.items())
     print(text)
-    for name, (loss_err, err, tensor) in report.items():
+    for name, (loss_err, err, tensor, median) in report.items():
         assert loss_err <= 2e-6, f"{name}: loss off by {loss_err:.2e} relative to float64 [{text}]"
-        assert err <= 5e-3, f"{name}: gradient of {tensor} is {err:.3e} of its rms away from float64 [{text}]"
+        assert median <= 2e-4, f"{name}: median gradient error {median:.3e} of the tensors' rms [{text}]"
+        assert err <= 3e-2, f"{name}: gradient of {tensor} is {err:.3e} of its rms away from float64 [{text}]"
 
 
 def test_graphed_train_step_equals_the_eager_loop_body():
