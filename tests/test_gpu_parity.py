@@ -293,6 +293,28 @@ def test_full_size_batch_properties(cond64, dev):
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
 
 
+def test_two_launches_on_the_whole_chip_are_bit_identical(cond64, dev):
+    """Full-chip grids (B = 64: 256 workgroups of the 8x8 stride-2 convolution, the fused attention tail of the last
+    decoder block, every split-K reduction) launched twice on the same inputs give the same bits: no result depends on
+    which workgroup or wave finishes first.  Checked on the convolution alone through its own entry point, with the
+    wave-role kernel and with fp32 instructions, and on the whole evaluation."""
+    model, _, ops = cond64
+    x = gs.randn(43, 64, 64, 32, 32).to(dev)
+    try:
+        for mode in (0, 1):
+            ops.lib.danra_set_fp32_products(mode)
+            a, b = ops.conv2_bn_relu(x), ops.conv2_bn_relu(x)
+            assert torch.equal(a, b), f"8x8 stride-2 convolution, fp32 products {mode}"
+    finally:
+        ops.lib.danra_set_fp32_products(0)
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 64, 64, seed=10).items()}
+    t = (torch.arange(64, device=dev) * 15) % 999 + 1
+    with torch.no_grad():
+        outs = [model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0]).all()
+
+
 def test_graph_replay_equals_enqueued_loop(cond64, dev):
     """The captured-step replay and the kernel-by-kernel loop are the same computation: bit-identical in both
     noise modes, with the trace taken between replays, and across a change of batch size (new capture)."""
