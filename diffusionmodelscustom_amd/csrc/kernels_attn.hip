@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     // [d][g][slot], slot 4j + r <-> key 16j + 4g + r of the half (the order in which a lane holds its 8 scores)
     __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
     __shared__ __attribute__((aligned(16))) _Float16 Kh[QKH ? 2 : 1][QKH ? KVT * KHROW : 8];
-    __shared__ int vbig_s;
+    // range flags, one per staging buffer: set (never cleared) by the threads that stage a tile into that buffer and read
+    // at the top of the iteration that consumes it.  With a single flag a wave that runs ahead could raise it for tile
+    // kt + 2 while a slower wave still decides about tile kt + 1, and which products that wave then used would depend on
+    // timing; a buffer's flag is only written again behind the barrier that ends the iteration that read it.
+    __shared__ int vbig_s[2];
     static_assert(PVH == QKH, "both products run on the fp16 matrix cores, or neither");
     constexpr float RESCALE = PVH ? 15.f : RESCALE_LOG2;  // log2 of the largest probability relative to the reference
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 16 + sc4]) = u32x2{l[0], l[1]};
             *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 32 + sc4]) = u32x2{sh[0], sh[1]};
             const float kmax = fmaxf(max3f(fabsf(kreg.x), fabsf(kreg.y), fabsf(kreg.z)), fabsf(kreg.w));
-            if (!(kmax < 32768.f)) vbig_s = 1;
+            if (!(kmax < 32768.f)) vbig_s[buf] = 1;
         }
         if (PVH) {
             unsigned h[2], l[2];
@@ -214,26 +218,28 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             *reinterpret_cast<u32x2*>(&Vh[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
             const float vmax = fmaxf(max3f(fabsf(vreg.x), fabsf(vreg.y), fabsf(vreg.z)), fabsf(vreg.w));
             // (a wave stages 16 keys x 16 columns.)  Never cleared: the tiles from this one on are multiplied in fp32
-            if (!(vmax < 32768.f) || __all(vmax < 0.0009765625f)) vbig_s = 1;
+            if (!(vmax < 32768.f) || __all(vmax < 0.0009765625f)) vbig_s[buf] = 1;
         }
     };
     if (PVH) {
-        if (tid == 0) vbig_s = 0;
+        if (tid < 2) vbig_s[tid] = 0;
         if (QKH) {  // the zero quarter of every key row, both buffers (the staging never touches it)
             const f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
             *reinterpret_cast<f16x4*>(&Kh[0][srow * KHROW + 48 + sc4]) = z;
             *reinterpret_cast<f16x4*>(&Kh[1][srow * KHROW + 48 + sc4]) = z;
         }
         __syncthreads();
-        if (QKH && !q_bounded) vbig_s = 1;
     }
     stage(0);
     __syncthreads();
 
     const int ntiles = L / KVT;
+    // fp32 products: always in the all-fp32 form; in the fp16 form from the first tile on for a wave whose own queries
+    // leave the fp16 range, and for every wave from the first flagged K / V tile on
+    bool vbig = PVH ? (__any(!q_bounded) != 0) : true;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = (ABL & 4) ? 0 : (kt & 1);
-        const bool vbig = PVH ? (__builtin_amdgcn_readfirstlane(vbig_s) != 0) : true;
+        vbig = vbig || (__builtin_amdgcn_readfirstlane(vbig_s[buf]) != 0);  // from the first flagged tile on
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
             kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
