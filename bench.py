@@ -304,7 +304,7 @@ def main():
             frac = peak_seconds / seconds
             assert frac <= 1.0, f"roofline fraction {frac} above 1: the peak does not bound the kernel it is quoted for"
             line["roofline"] = {
-                "kernel": name + ": HIP events attached to every dispatch of the family (they carry the kernel's own begin and end times) in every 8th denoise step of the timed region",
+                "kernel": name + ": HIP events attached to every dispatch of the family (they carry the kernel's own begin and end times) in every 64th denoise step of the timed region",
                 "bound": "mfma",
                 "achieved": executed_tflops,
                 "peak": blended_peak,

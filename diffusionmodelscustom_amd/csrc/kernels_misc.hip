@@ -975,11 +975,13 @@ hipError_t launch_pack_conv(const float* w, const float* scale, float* out, int 
     return hipGetLastError();
 }
 
+// max |w| of a tensor into *out, which the caller has zeroed (infinity for a tensor that holds a NaN or an infinity).
+// Non-negative floats order like their bit patterns, so the blocks combine their maxima with an integer atomic max.
 __global__ __launch_bounds__(256) void k_maxabs(const float* __restrict__ w, size_t n, float* __restrict__ out) {
     __shared__ float red[256];
     float m = 0.f;
     bool bad = false;
-    for (size_t i = threadIdx.x; i < n; i += 256) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = fabsf(w[i]);
         bad = bad || !(v <= 3.0e38f);  // NaN or infinity
         m = fmaxf(m, v);
@@ -990,10 +992,14 @@ __global__ __launch_bounds__(256) void k_maxabs(const float* __restrict__ w, siz
         if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0];
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(red[0]));
 }
 hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_maxabs, dim3(1), dim3(256), 0, stream, w, n, out);
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    int blocks = (int)((n + 4095) / 4096);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(k_maxabs, dim3(blocks), dim3(256), 0, stream, w, n, out);
     return hipGetLastError();
 }
 

@@ -214,7 +214,7 @@ int danra_set_graph_mode(danra_handle_t h, int enable);
  * _end every launch of the named kernel family is bracketed by HIP events on the stream it is launched
  * on.  _end waits for the last event (host sync) and returns the summed kernel time, the number of
  * launches and their algorithmic FLOPs (2 per multiply-add of QK^T and PV).  danra_unet_forward times every
- * launch; danra_sample times the launches of every 8th denoise step (that step is enqueued kernel by kernel, the
+ * launch; danra_sample times the launches of every 64th denoise step (that step is enqueued kernel by kernel, the
  * others are replayed from the graph as usual), so that the event records do not slow the loop being measured. */
 #define DANRA_PROF_FLASH_ATTENTION 1 /* the flash attention kernels (head_dim 16; head_dim 32/64 with 2 heads or 1 head) */
 #define DANRA_PROF_IGEMM 2           /* the implicit-GEMM family: every convolution (but the stem's x plane), transposed
