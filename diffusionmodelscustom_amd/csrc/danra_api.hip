@@ -1191,6 +1191,21 @@ int danra_instancenorm_bwd(const float* x, const float* dy, const float* save_me
     return DANRA_OK;
 }
 
+int danra_linear_wgrad_supported(int M, int N, int K) { return linear_wgrad_supported(M, N, K) ? 1 : 0; }
+
+size_t danra_linear_wgrad_workspace(int M, int N, int K) {
+    return linear_wgrad_supported(M, N, K) ? linear_wgrad_workspace_floats(M, N, K) * sizeof(float) : 0;
+}
+
+int danra_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, void* workspace,
+                       void* stream) {
+    if (!dy || !x || !dw || !workspace) return fail(DANRA_EINVAL, "null argument");
+    if (!linear_wgrad_supported(M, N, K))
+        return fail(DANRA_EINVAL, "M=%d N=%d K=%d: supported are K = 64 with N = 64, 128 or 192 and M > 0", M, N, K);
+    HIP_TRY(launch_linear_wgrad(dy, x, dw, db, M, N, K, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,

@@ -210,6 +210,12 @@ hipError_t launch_in_train_fwd(const float* x, float* y, float* save_mean, float
                                hipStream_t stream);
 hipError_t launch_in_train_bwd(const float* x, const float* dy, const float* save_mean, const float* save_rstd, float* dx,
                                int planes, int HW, hipStream_t stream);
+// dW = dY^T X, db = column sums of dY (linear layer over M rows; K = 64, N = 64 / 128 / 192).  `workspace`:
+// linear_wgrad_workspace_floats(M, N, K) floats.
+size_t linear_wgrad_workspace_floats(int M, int N, int K);
+bool linear_wgrad_supported(int M, int N, int K);
+hipError_t launch_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* workspace,
+                               hipStream_t stream);
 
 // ---------------------------------------------------------------- weight packing
 // max |w| over n floats -> *out (one float; not atomic across launches: one launch per destination)

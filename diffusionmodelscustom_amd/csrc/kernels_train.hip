@@ -4,6 +4,7 @@
 // One workgroup per channel.  A channel's B*HW values (a few thousand to a few ten thousand at the network's sizes) are
 // walked three times in the forward pass (sum -> centred sum of squares -> normalise) and twice in the backward pass; after
 // the first walk they come from L2.  Two-pass statistics: the biased variance equals a direct evaluation, as in torch.
+#include <type_traits>
 #include "danra_kernels.h"
 
 namespace danra {
@@ -221,6 +222,205 @@ hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, 
     if (HW % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bn_train_bwd, dim3(C), dim3(256), 0, stream, x, dy, y, gamma, save_mean, save_rstd, dx, dgamma, dbeta,
                        B, C, HW, relu);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a linear layer over tokens: dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]
+// (torch.nn.functional.linear backward for y = x W^T + b; the attention projections of the 64-channel levels:
+// M = batch x tokens = 8192 ... 131072 rows, N = 64 or 192, K = 64).  A GEMM whose reduction runs over the long
+// dimension and whose result is tiny: the rows are cut into slices, one workgroup per slice forms the whole N x K
+// product of its rows, and a second kernel adds the slices in a fixed order (bitwise reproducible).
+//
+// Both operands are read straight from memory in their natural layout: for v_mfma_f32_32x32x2_f32 lane (i, h)
+// supplies A[i][k = h] and B[k = h][j = i], and here the reduction index k is the row m, so lanes 0-31 read row m,
+// lanes 32-63 row m + 1, each lane WF consecutive floats of it (one dwordx4 / dwordx2 load): component c of that
+// load is the operand of a 32 x 32 tile whose rows are the columns n = base + WF i + c of dY - the tiles interleave
+// in n, which only matters when the result is written out.  The N/32 x K/32 tiles are dealt to the four waves
+// (three each for N = 192), every wave walks all row pairs of the slice, eight pairs per batch of loads with the next
+// batch in flight behind the matrix instructions of the current one, and writes its tiles itself: no LDS, no barrier.
+template <int NF, int KF, int W>  // N = 32 NF, K = 32 KF, W = wave
+__device__ __forceinline__ void wgrad_wave(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ pw,
+                                           float* __restrict__ pb, int m_begin, int m_end, int lane) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int N = 32 * NF, K = 32 * KF;
+    constexpr int NA4 = NF / 4, NA2 = (NF % 4) / 2, NA1 = NF % 2;  // pieces of a dY row: 128, 64 and 32 columns wide
+    constexpr int KB4 = KF / 4, KB2 = (KF % 4) / 2, KB1 = KF % 2;  // ... of an X row
+    constexpr int TPW = NF * KF / 4, T0 = W * TPW;                // this wave's tiles: t = a KF + b, T0 <= t < T0 + TPW
+    static_assert((NF * KF) % 4 == 0, "tiles are dealt evenly to four waves");
+    constexpr int U = 8;  // row pairs per batch of loads
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum[NF];  // db share of the tiles (a, 0) this wave owns: column base + WF i + c, this lane's row parity
+#pragma unroll
+    for (int a = 0; a < NF; ++a) bsum[a] = 0.f;
+    float ra[2][U][NF], rb[2][U][KF];
+
+    auto load_batch = [&](auto buf_tag, int sp0) {
+        constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m_begin + 2 * (sp0 + u) + h;
+            const bool live = m < m_end;  // (past the slice, or the second row of an odd tail: zeros)
+            const float* yrow = dY + (size_t)(live ? m : m_end - 1) * N;
+            const float* xrow = X + (size_t)(live ? m : m_end - 1) * K;
+            int o = 0;
+#pragma unroll
+            for (int p = 0; p < NA4; ++p) {
+                const float4 v = *reinterpret_cast<const float4*>(yrow + 128 * p + 4 * i);
+                ra[BUF][u][o++] = v.x; ra[BUF][u][o++] = v.y; ra[BUF][u][o++] = v.z; ra[BUF][u][o++] = v.w;
+            }
+#pragma unroll
+            for (int p = 0; p < NA2; ++p) {
+                const float2 v = *reinterpret_cast<const float2*>(yrow + 128 * NA4 + 64 * p + 2 * i);
+                ra[BUF][u][o++] = v.x; ra[BUF][u][o++] = v.y;
+            }
+            if (NA1) ra[BUF][u][o++] = yrow[128 * NA4 + 64 * NA2 + i];
+            o = 0;
+#pragma unroll
+            for (int p = 0; p < KB4; ++p) {
+                const float4 v = *reinterpret_cast<const float4*>(xrow + 128 * p + 4 * i);
+                rb[BUF][u][o++] = v.x; rb[BUF][u][o++] = v.y; rb[BUF][u][o++] = v.z; rb[BUF][u][o++] = v.w;
+            }
+#pragma unroll
+            for (int p = 0; p < KB2; ++p) {
+                const float2 v = *reinterpret_cast<const float2*>(xrow + 128 * KB4 + 64 * p + 2 * i);
+                rb[BUF][u][o++] = v.x; rb[BUF][u][o++] = v.y;
+            }
+            if (KB1) rb[BUF][u][o++] = xrow[128 * KB4 + 64 * KB2 + i];
+            // only dY needs the zeros: a product with a zero operand contributes nothing whatever X holds (finite: it
+            // is a row of the slice)
+#pragma unroll
+            for (int a = 0; a < NF; ++a) ra[BUF][u][a] = live ? ra[BUF][u][a] : 0.f;
+        }
+    };
+    auto multiply_batch = [&](auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int a = (T0 + t) / KF, b = (T0 + t) % KF;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[BUF][u][a], rb[BUF][u][b], acc[t], 0, 0, 0);
+                if (b == 0) bsum[a] += ra[BUF][u][a];
+            }
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    const int pairs = (m_end - m_begin + 1) / 2;
+    load_batch(B0{}, 0);
+    for (int sp = 0; sp < pairs; sp += 2 * U) {
+        load_batch(B1{}, sp + U);
+        multiply_batch(B0{});
+        load_batch(B0{}, sp + 2 * U);
+        multiply_batch(B1{});
+    }
+
+    // column of dY (row of dW) that tile a holds in its row ii, and column of X that tile b holds in its column jj
+    auto n_of = [&](int a, int ii) {
+        if (a < 4 * NA4) return 128 * (a / 4) + 4 * ii + (a % 4);
+        if (a < 4 * NA4 + 2 * NA2) return 128 * NA4 + 64 * ((a - 4 * NA4) / 2) + 2 * ii + ((a - 4 * NA4) % 2);
+        return 128 * NA4 + 64 * NA2 + ii;
+    };
+    auto k_of = [&](int b, int jj) {
+        if (b < 4 * KB4) return 128 * (b / 4) + 4 * jj + (b % 4);
+        if (b < 4 * KB4 + 2 * KB2) return 128 * KB4 + 64 * ((b - 4 * KB4) / 2) + 2 * jj + ((b - 4 * KB4) % 2);
+        return 128 * KB4 + 64 * KB2 + jj;
+    };
+    // acc[t][r] = D[row (r & 3) + 8 (r >> 2) + 4 h][column i]
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int a = (T0 + t) / KF, b = (T0 + t) % KF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[n_of(a, (r & 3) + 8 * (r >> 2) + 4 * h) * K + k_of(b, i)] = acc[t][r];
+        if (b == 0 && pb) {
+            const float both = bsum[a] + __shfl_xor(bsum[a], 32);  // the two rows of a pair
+            if (h == 0) pb[n_of(a, i)] = both;
+        }
+    }
+}
+
+template <int NF, int KF>
+__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+                                                      float* __restrict__ part_w, float* __restrict__ part_b, int M,
+                                                      int rows_per_wg) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m_begin = blockIdx.x * rows_per_wg;
+    const int m_end = min(M, m_begin + rows_per_wg);
+    float* pw = part_w + (size_t)blockIdx.x * (32 * NF) * (32 * KF);
+    float* pb = part_b ? part_b + (size_t)blockIdx.x * (32 * NF) : nullptr;
+    if (wave == 0) wgrad_wave<NF, KF, 0>(dY, X, pw, pb, m_begin, m_end, lane);
+    else if (wave == 1) wgrad_wave<NF, KF, 1>(dY, X, pw, pb, m_begin, m_end, lane);
+    else if (wave == 2) wgrad_wave<NF, KF, 2>(dY, X, pw, pb, m_begin, m_end, lane);
+    else wgrad_wave<NF, KF, 3>(dY, X, pw, pb, m_begin, m_end, lane);
+}
+
+// out[q] = sum over the slices of part[s * count + q], four values per thread.  A block owns 32 float4 columns and
+// eight lanes per column: lane g adds slices g, g + 8, ... (eight loads in flight), the eight sums are added in lane
+// order through LDS - a fixed order whatever the timing.
+__global__ __launch_bounds__(256) void k_sum_slices(const float* __restrict__ part, float* __restrict__ out, int count4,
+                                                    int slices) {
+    __shared__ float4 red[8][32];
+    const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int q = blockIdx.x * 32 + col;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < count4) {
+        const float4* p = reinterpret_cast<const float4*>(part) + q;
+        for (int s0 = g; s0 < slices; s0 += 64) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(s0 + 8 * u, slices - 1) * count4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + 8 * u < slices) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    red[g][col] = acc;
+    __syncthreads();
+    if (g == 0 && q < count4) {
+        float4 t = red[0][col];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) { t.x += red[u][col].x; t.y += red[u][col].y; t.z += red[u][col].z; t.w += red[u][col].w; }
+        reinterpret_cast<float4*>(out)[q] = t;
+    }
+}
+
+static int wgrad_slices(int M) {
+    // one slice per CU where the rows allow it; a slice is a multiple of 8 rows (4 waves x 2 rows) and at least 64
+    int rows = (M + 255) / 256;
+    rows = (rows + 7) / 8 * 8;
+    if (rows < 64) rows = 64;
+    return rows;
+}
+size_t linear_wgrad_workspace_floats(int M, int N, int K) {
+    const int rows = wgrad_slices(M);
+    const size_t slices = (size_t)(M + rows - 1) / rows;
+    return slices * ((size_t)N * K + N);
+}
+bool linear_wgrad_supported(int M, int N, int K) { return M > 0 && K == 64 && (N == 64 || N == 128 || N == 192); }
+
+hipError_t launch_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* workspace,
+                               hipStream_t stream) {
+    if (!linear_wgrad_supported(M, N, K)) return hipErrorInvalidValue;
+    const int rows = wgrad_slices(M);
+    const int slices = (M + rows - 1) / rows;
+    float* part_w = workspace;
+    float* part_b = db ? workspace + (size_t)slices * N * K : nullptr;
+    if (N == 192) hipLaunchKernelGGL((k_linear_wgrad<6, 2>), dim3(slices), dim3(256), 0, stream, dy, x, part_w, part_b, M, rows);
+    else if (N == 128) hipLaunchKernelGGL((k_linear_wgrad<4, 2>), dim3(slices), dim3(256), 0, stream, dy, x, part_w, part_b, M, rows);
+    else hipLaunchKernelGGL((k_linear_wgrad<2, 2>), dim3(slices), dim3(256), 0, stream, dy, x, part_w, part_b, M, rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sum_slices, dim3((N * K / 4 + 31) / 32), dim3(256), 0, stream, part_w, dw, N * K / 4, slices);
+    if (db) hipLaunchKernelGGL(k_sum_slices, dim3((N / 4 + 31) / 32), dim3(256), 0, stream, part_b, db, N / 4, slices);
     return hipGetLastError();
 }
 

@@ -69,6 +69,9 @@ _SIGNATURES = {
                                                  ctypes.c_int, _P]),
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "danra_linear_wgrad_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "danra_linear_wgrad": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_set_first_image": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
@@ -242,15 +245,60 @@ def attention_core_supported(tokens, n_heads):
             and tokens.shape[0] * n_heads * tokens.shape[1] < (1 << 27))
 
 
+class _TokenLinear(torch.autograd.Function):
+    """torch.nn.functional.linear(x, weight, bias) on [..., K] fp32 CUDA tokens whose weight and bias gradients are formed
+    in libdanra_hip.so (danra_linear_wgrad): grad_weight = dy^T x is a product with a few thousand output values and a
+    reduction over every token of the batch (8192 ... 131072 rows), which the BLAS library behind torch.mm runs at 60-130 us
+    per call on MI355X; the forward product and the input gradient stay torch's."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = _f32(dy, "dy").reshape(-1, N)
+        x2 = x.reshape(-1, K).contiguous()
+        M = x2.shape[0]
+        dx = dy2.matmul(weight).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db) if db is not None else None, M, N, K,
+                                               _ptr(workspace), _stream()), "danra_linear_wgrad")
+        return dx, dw, db
+
+
+def token_linear(x, weight, bias):
+    """``torch.nn.functional.linear`` whose weight gradient may be formed by the native library (see _TokenLinear): on
+    CUDA, float32 parameters, a layer shape the kernel has (K = 64, N = 64 / 128 / 192), with the native training kernels
+    enabled; torch's own operator otherwise."""
+    if (native_training_kernels and x.is_cuda and weight.dtype == torch.float32 and weight.requires_grad
+            and bias is not None and torch.is_grad_enabled()):
+        N, K = weight.shape
+        M = x.numel() // K
+        if load_library().danra_linear_wgrad_supported(M, N, K):
+            return _TokenLinear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def differentiable_self_attention(mha, tokens):
     """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module:
-    the two projections as torch ops (autograd handles them), the scaled-dot-product core in the native library."""
+    the two projections as torch products (their weight gradients in the native library), the scaled-dot-product core
+    in the native library."""
     B, L, C = tokens.shape
     heads = mha.num_heads
-    qkv = torch.nn.functional.linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
+    qkv = token_linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
     qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # made contiguous (and float32) by the core
     attended = _AttentionCoreHD16.apply(qkv)
-    return torch.nn.functional.linear(attended, mha.out_proj.weight, mha.out_proj.bias)
+    return token_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
 
 
 class _BatchNormTrain(torch.autograd.Function):

@@ -197,6 +197,16 @@ int danra_instancenorm_fwd(const float* x_dev, float* y_dev, float* save_mean_de
 int danra_instancenorm_bwd(const float* x_dev, const float* dy_dev, const float* save_mean_dev, const float* save_rstd_dev,
                            float* dx_dev, int planes, int HW, void* stream);
 
+/* Weight and bias gradient of y = x W^T + b over M rows (torch.nn.functional.linear's backward for its weight and bias, as
+ * autograd runs it for the attention projections nn.MultiheadAttention holds, modules_DANRA_conditional.py:84,105, in the
+ * training step training_DANRA_conditional.py:962-984): dw[N][K] = dy^T x, db[N] = column sums of dy (db may be NULL).
+ * dy: [M][N], x: [M][K], row-major fp32.  Supported: K = 64 and N = 64, 128 or 192 (danra_linear_wgrad_supported);
+ * workspace: danra_linear_wgrad_workspace(M, N, K) bytes of device memory, the caller's (nothing is allocated). */
+int danra_linear_wgrad_supported(int M, int N, int K);
+size_t danra_linear_wgrad_workspace(int M, int N, int K);
+int danra_linear_wgrad(const float* dy_dev, const float* x_dev, float* dw_dev, float* db_dev, int M, int N, int K,
+                       void* workspace_dev, void* stream);
+
 /* Batch sharding of the in-kernel noise (no counterpart in the reference, which samples on one device): the calls
  * to danra_sample / danra_sample_guided that follow treat their image 0 as image `first_image` of a larger batch:
  * with DANRA_NOISE_PHILOX the draw for element e of local image b at a timestep is that of global element

@@ -419,16 +419,76 @@ def test_batchnorm_train_kernels_match_torch(shape, relu):
     assert int(gpu.num_batches_tracked) == int(ref.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("M,N", [(32768, 192), (8192, 64), (4096 + 6, 128), (131072, 192), (70, 64), (1, 192)])
+def test_linear_weight_gradient_kernel_against_float64(M, N):
+    """danra_linear_wgrad (dW = dy^T x, db = column sums of dy over M token rows) against a float64 evaluation: the
+    attention projections' shapes at batch 32 (1024 and 256 tokens) and batch 32 at 4096 tokens, a row count that is
+    neither even per slice nor a multiple of the slice, and fewer rows than one slice.  Per-op bar 1e-5 of the largest
+    value; two calls give the same bits."""
+    K = 64
+    lib = hip_engine.load_library()
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g)
+    x = torch.randn(M, K, generator=g) + 0.5
+    want_w = dy.double().t() @ x.double()
+    want_b = dy.double().sum(0)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    assert lib.danra_linear_wgrad_supported(M, N, K) == 1
+    ws = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        rc = lib.danra_linear_wgrad(ctypes.c_void_p(dyd.data_ptr()), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(dw.data_ptr()),
+                                    ctypes.c_void_p(db.data_ptr()), M, N, K, ctypes.c_void_p(ws.data_ptr()), None)
+        assert rc == 0, lib.danra_last_error()
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(outs[0][0], want_w, 1e-5, "dW")
+    close(outs[0][1], want_b, 1e-5, "db")
+    # without a bias gradient; refusals
+    dw = torch.empty(N, K, device=DEV)
+    assert lib.danra_linear_wgrad(ctypes.c_void_p(dyd.data_ptr()), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(dw.data_ptr()),
+                                  None, M, N, K, ctypes.c_void_p(ws.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), outs[0][0])
+    assert lib.danra_linear_wgrad_supported(M, N, 128) == 0 and lib.danra_linear_wgrad_supported(M, 96, K) == 0
+    assert lib.danra_linear_wgrad(ctypes.c_void_p(dyd.data_ptr()), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(dw.data_ptr()),
+                                  None, M, 96, K, ctypes.c_void_p(ws.data_ptr()), None) == -1
+    assert lib.danra_linear_wgrad(None, ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(dw.data_ptr()), None, M, N, K,
+                                  ctypes.c_void_p(ws.data_ptr()), None) == -1
+
+
+def test_token_linear_equals_torch_linear():
+    """hip_engine.token_linear against torch.nn.functional.linear: same forward bits, gradients within 1e-5 (the weight
+    and bias gradients come from the native kernel, the input gradient from torch)."""
+    torch.manual_seed(5)
+    x = torch.randn(4, 1024, 64, device=DEV, requires_grad=True)
+    w = torch.randn(192, 64, device=DEV, requires_grad=True)
+    b = torch.randn(192, device=DEV, requires_grad=True)
+    up = torch.randn(4, 1024, 192, device=DEV)
+    y0 = torch.nn.functional.linear(x, w, b)
+    g0 = torch.autograd.grad(y0, (x, w, b), up)
+    y1 = hip_engine.token_linear(x, w, b)
+    g1 = torch.autograd.grad(y1, (x, w, b), up)
+    assert torch.equal(y0, y1)
+    for a, c, name in zip(g1, g0, ("dx", "dw", "db")):
+        close(a.cpu(), c.cpu(), 1e-5, name)
+
+
 def native_call_counters(monkeypatch):
     names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
-             "danra_instancenorm_fwd", "danra_instancenorm_bwd")
+             "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
-# the conditional network: 4 attention blocks at 64 channels; bn1 + 8 blocks x 2 + 3 shortcut norms; 4 decoder blocks x 2
-# InstanceNorms + the final block's first (its second is an Identity)
+# the conditional network: 4 attention blocks at 64 channels (core forward and backward, and the weight gradients of their
+# two projections); bn1 + 8 blocks x 2 + 3 shortcut norms; 4 decoder blocks x 2 InstanceNorms + the final block's first
+# (its second is an Identity)
 EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 20,
-                         "danra_batchnorm_train_bwd": 20, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9}
+                         "danra_batchnorm_train_bwd": 20, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
+                         "danra_linear_wgrad": 8}
 
 
 def test_train_mode_network_uses_the_native_kernels(monkeypatch):
