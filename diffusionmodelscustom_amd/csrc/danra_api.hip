@@ -130,6 +130,7 @@ struct danra_handle_s {
     AttnP attn[9];
     DecP dec[4];
     float *final_wt = nullptr, *final_bt = nullptr;
+    SplitW final_s_wt;
     float *tw = nullptr, *tb = nullptr;  // time projections [tb_width][dim], [tb_width]
     float* label_emb = nullptr;
     float *enc_inv_freq = nullptr, *dec_div = nullptr;
@@ -266,6 +267,7 @@ struct SplitJob {
     const float* w;
     size_t n;
     SplitW* dst;
+    bool frag64;  // rows of 64 weights in the fragment order of the row-stationary K = 64 GEMM
 };
 
 // Lays out (and on the second pass fills) the packed arena; `bh` lays out the arena of split-operand copies.
@@ -273,11 +275,12 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
     const int dim = h->cfg.time_embedding;
     // k_igemm's split-operand form needs rows of whole 64-deep chunks and pays from K = 128 on (the K = 64 products
     // go through the row-stationary kernels, which are bound by memory, not by the matrix cores)
-    auto want_split = [&](SplitW& s, float* w, size_t rows, size_t K) {
+    // (K = 64 only where asked for: the token projections that go through k_gemm_k64, which has a layout of its own)
+    auto want_split = [&](SplitW& s, float* w, size_t rows, size_t K, bool k64 = false) {
         s = SplitW();
-        if (K % 64 || K < 128) return;
+        if (K % 64 || (K < 128 && !(k64 && K == 64))) return;
         s.wh = bh.take(rows * K);
-        jobs.push_back({w, rows * K, &s});
+        jobs.push_back({w, rows * K, &s, K == 64});
     };
     float* scratch_scale = bp.take(512);
     auto pack_conv_bn = [&](ConvP& c, const std::string& wname, const std::string& bn, int Cin, int Cout, int k,
@@ -300,15 +303,15 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         a.b_in = bp.take((size_t)3 * C);
         a.w_out = bp.take((size_t)C * C);
         a.b_out = bp.take(C);
-        want_split(a.s_in, a.w_in, (size_t)3 * C, C);
-        want_split(a.s_out, a.w_out, C, C);
+        want_split(a.s_in, a.w_in, (size_t)3 * C, C, true);
+        want_split(a.s_out, a.w_out, C, C, true);
         if (h->cfg.attn_ff) {
             a.w_ff1 = bp.take((size_t)C * C);
             a.b_ff1 = bp.take(C);
             a.w_ff2 = bp.take((size_t)C * C);
             a.b_ff2 = bp.take(C);
-            want_split(a.s_ff1, a.w_ff1, C, C);
-            want_split(a.s_ff2, a.w_ff2, C, C);
+            want_split(a.s_ff1, a.w_ff1, C, C, true);
+            want_split(a.s_ff2, a.w_ff2, C, C, true);
         }
         if (fill) {
             const std::string m = p + mha_name(h);
@@ -410,7 +413,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         d.conv.Cin = d.Cin; d.conv.Cout = d.Cout; d.conv.KH = d.conv.KW = 3; d.conv.stride = 1; d.conv.pad = 1;
         d.conv.w = bp.take((size_t)d.Cout * d.Cin * 9);
         d.conv.bias = bp.take(d.Cout);
-        want_split(d.s_wt, d.wt, (size_t)4 * d.Cin, d.Cin);
+        want_split(d.s_wt, d.wt, (size_t)4 * d.Cin, d.Cin, true);
         want_split(d.conv.split, d.conv.w, d.Cout, (size_t)9 * d.Cin);
         if (fill) {
             HIP_TRY(launch_pack_convT(src_of(h, p + ".transpose.weight"), src_of(h, p + ".transpose.bias"), d.wt, d.bt,
@@ -426,6 +429,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         h->attn[5 + k] = d.attn;
     }
     h->final_wt = bp.take((size_t)4 * 64 * 64);
+    want_split(h->final_s_wt, h->final_wt, (size_t)4 * 64, 64, true);
     h->final_bt = bp.take(4 * 64);
     h->final_conv.Cin = 64; h->final_conv.Cout = h->cfg.out_channels; h->final_conv.KH = h->final_conv.KW = 3;
     h->final_conv.stride = 1; h->final_conv.pad = 1;
@@ -464,7 +468,7 @@ int split_registered(danra_handle_s* h, std::vector<SplitJob>& jobs, float* maxi
         int s = 13 - e;                  // 2^s * mx in [2^12, 2^13)
         s = s > 100 ? 100 : (s < -100 ? -100 : s);
         jobs[i].dst->inv_scale = ldexpf(1.0f, -s);
-        HIP_TRY(launch_split_weights(jobs[i].w, jobs[i].dst->wh, jobs[i].n, ldexpf(1.0f, s), st));
+        HIP_TRY(launch_split_weights(jobs[i].w, jobs[i].dst->wh, jobs[i].n, ldexpf(1.0f, s), st, jobs[i].frag64));
     }
     return DANRA_OK;
 }
@@ -717,7 +721,7 @@ int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
 // in the same kernel as the output projection: ct_out receives [B][2*ct_H][2*ct_W][64] and `out` is not written.
 int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st,
                   const float* ct_w = nullptr, const float* ct_b = nullptr, float* ct_out = nullptr, int ct_H = 0,
-                  int ct_W = 0) {
+                  int ct_W = 0, const SplitW* ct_split = nullptr) {
     const AttnP& at = h->attn[index];
     const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
     Workspace& ws = h->ws;
@@ -748,9 +752,14 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     const bool ff = at.w_ff1 != nullptr;
     if (ct_w && C != 64) return fail(DANRA_EINVAL, "fused transposed convolution needs a 64-channel block");
     if (C == 64 && (ff || ct_w)) {  // the row-local GEMMs behind the attention core of a 64-channel block run as one kernel
+        Tail64Split sp;
+        sp.wo = at.s_out.wh; sp.so = at.s_out.inv_scale;
+        sp.w1 = at.s_ff1.wh; sp.s1 = at.s_ff1.inv_scale;
+        sp.w2 = at.s_ff2.wh; sp.s2 = at.s_ff2.inv_scale;
+        if (ct_split) { sp.wt = ct_split->wh; sp.st = ct_split->inv_scale; }
         HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, ct_w, ct_b,
                                    ct_w ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W,
-                                   ct_w ? ws.stats_part : nullptr, st));
+                                   ct_w ? ws.stats_part : nullptr, st, &sp));
         return DANRA_OK;
     }
     float* attended = ff ? ws.qkv : out;
@@ -842,7 +851,7 @@ int run_time_mlp(danra_handle_s* h, const int64_t* t, SampleState* state, const 
 // next_wt/next_bt: apply the NEXT block's transposed convolution to this block's output (into ws.up, `out` unused).
 int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* skip, const float* tbias, float* out,
                       int B, int Hh, int Ww, hipStream_t st, bool up_ready = false, const float* next_wt = nullptr,
-                      const float* next_bt = nullptr) {
+                      const float* next_bt = nullptr, const SplitW* next_split = nullptr) {
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
@@ -860,7 +869,7 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     HIP_TRY(launch_in_stats(slabs.count ? ws.partial : ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B,
                             H2 * W2, d.Cout, st, ws.pre, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width,
                             slabs.count ? &slabs : nullptr));
-    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2));
+    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2, next_split));
     return DANRA_OK;
 }
 
@@ -868,7 +877,7 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
                     bool up_ready = false) {
     Workspace& ws = h->ws;
     if (!up_ready) {
-        RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st));
+        RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st, &h->final_s_wt));
         HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
     } else if (final_conv_merges_slices(2 * Hh, 2 * Ww, 64)) {
         // the producer of ws.up left its statistics in slices of 32 samples; the convolution merges them itself
@@ -918,12 +927,15 @@ int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleStat
     for (int k = 0; k < 4; ++k) {
         float* dout = (k & 1) ? ws.outB : ws.outA;
         const float *next_wt = nullptr, *next_bt = nullptr;
+        const SplitW* next_split = nullptr;
         // (measured: pays from 32768 token rows on; below that the per-workgroup weight staging outweighs the saved pass)
         if (h->dec[k].Cout == 64 && (long)B * 4 * Hc * Wc >= 32768) {
             next_wt = (k < 3) ? h->dec[k + 1].wt : h->final_wt;
             next_bt = (k < 3) ? h->dec[k + 1].bt : h->final_bt;
+            next_split = (k < 3) ? &h->dec[k + 1].s_wt : &h->final_s_wt;
         }
-        RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st, up_ready, next_wt, next_bt));
+        RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st, up_ready, next_wt, next_bt,
+                                 next_split));
         up_ready = next_wt != nullptr;
         din = dout;
         Hc *= 2; Wc *= 2;

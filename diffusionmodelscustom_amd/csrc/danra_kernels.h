@@ -90,9 +90,17 @@ bool igemm_uses_split(const IGemmArgs& a);
 // With Wt and `part` (M and ct_H*ct_W multiples of 32) the kernel also leaves the InstanceNorm statistics of its output in
 // slices: part[image][S = ct_H*ct_W/8][{mean, centred sum of squares}][64], 32 samples per slice, for
 // launch_in_stats_from_slices.  At least one of W1 and Wt must be given.
+// `split` (optional): the matrices split in fp16 halves in fragment order (launch_split_weights with frag64) and the
+// inverse of each one's power-of-two scale; the chain then multiplies on the fp16 matrix cores (fp32 results, fp32
+// instructions for rows out of the split's range).
+struct Tail64Split {
+    const float *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *wt = nullptr;
+    float so = 1.f, s1 = 1.f, s2 = 1.f, st = 1.f;
+};
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream);
+                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream,
+                              const Tail64Split* split = nullptr);
 
 // One input plane's share of the 8x8 stride-2 pad-3 stem: out = conv(x; Wt[64][8x8], row stride ldw) [+ res] [+ tbias[b]],
 // x: [B][H][W], out/res: [B][H/2][W/2][64]; H and W multiples of 16.
@@ -223,7 +231,7 @@ hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t strea
 // Split-operand form of a packed weight matrix for k_igemm's HALF variant: n floats (rows of K, K a multiple of 64) ->
 // n float-sized slots; every 64 consecutive weights w become [64 halves hi | 64 halves lo] of scale * w with
 // hi = fp16(scale*w) (rounded towards zero) and lo = fp16(scale*w - hi).  `scale` is a power of two.
-hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream);
+hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream, bool frag64 = false);
 hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                           float* scale, float* shift, int C, hipStream_t stream);
 hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_ohwi, int O, int I, int KH, int KW,

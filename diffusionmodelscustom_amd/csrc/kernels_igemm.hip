@@ -37,6 +37,10 @@ __device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
 
 static constexpr int BN = 64;
 
+// process-wide switch: every product of this file with fp32 matrix instructions (danra_set_fp32_products)
+static int g_igemm_fp32_products = 0;
+void set_igemm_fp32_products(int on) { g_igemm_fp32_products = on ? 1 : 0; }
+
 // x / d for x >= 0, d > 0: a shift when the host found d to be a power of two (sh = its log2, else -1).  Every
 // feature map of the networks this library runs has power-of-two sides; an integer division by a run-time value
 // costs some forty instructions, and the set-up of a workgroup does a dozen of them before its first load.
@@ -837,7 +841,70 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const IGemmArgs p) {
 // instructions than the row-major accumulator layout, and the lane's own row offset serves them all.
 // With no barrier in the walk the waves of a CU drift apart, so loads, matrix work and stores of
 // different waves overlap.
-template <int NW4>  // weight float4 loads a thread keeps in flight
+// ---- fragment helpers of the K = 64 kernels (k_gemm_k64, k_attn_tail64).  A wave holds 32 rows of 64 values as
+// float4 a[8]: lane (row, h) has k = 8 u + 4 h .. + 3 in a[u].
+// The split-operand form of those rows: k-step s takes a[2s] and a[2s + 1], i.e. k = 16 s + 4 h + {0..3, 8..11}, the
+// order in which launch_split_weights(frag64) lays out the halves of a weight row.  Returns (wave-uniform) whether
+// the rows are in the range where the split keeps 22 bits: nothing at or above 2^15 (or non-finite), and something at
+// or above 2^-8 unless all is zero.
+__device__ __forceinline__ bool split_frag64(const float4 (&a)[8], f16x8 (&ah)[4], f16x8 (&al)[4]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a[kb].x), fabsf(a[kb].y))), fmaxf(fabsf(a[kb].z), fabsf(a[kb].w)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        unsigned hi[4], lo[4];
+        split_pair_f16(a[2 * st].x, a[2 * st].y, hi[0], lo[0]);
+        split_pair_f16(a[2 * st].z, a[2 * st].w, hi[1], lo[1]);
+        split_pair_f16(a[2 * st + 1].x, a[2 * st + 1].y, hi[2], lo[2]);
+        split_pair_f16(a[2 * st + 1].z, a[2 * st + 1].w, hi[3], lo[3]);
+        ah[st] = __builtin_bit_cast(f16x8, (u32x4){hi[0], hi[1], hi[2], hi[3]});
+        al[st] = __builtin_bit_cast(f16x8, (u32x4){lo[0], lo[1], lo[2], lo[3]});
+    }
+    return !__any(!(amax < 32768.f)) && (__any(amax >= 0.00390625f) || !__any(amax > 0.f));
+}
+// One 32-column tile of W a^T (weights as the MFMA A operand: the product comes out transposed).  Bs = the tile's
+// first weight row + this lane's row and half: in the split form a row holds [64 halves hi | 64 halves lo] and
+// halves (2 s + h) 8 .. + 7 start at float 8 s + 4 h.
+__device__ __forceinline__ f32x16 tile64_half(const float* Bs, const f16x8 (&ah)[4], const f16x8 (&al)[4]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(Bs + st * 8);
+        const f16x8 wl = *reinterpret_cast<const f16x8*>(Bs + st * 8 + 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah[st], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 tile64_f32(const float* Bs, const float4 (&a)[8]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[kb].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[kb].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[kb].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// HALF: the products run as split-operand fp16 products (see k_igemm) on v_mfma_f32_32x32x16_f16: 72 matrix
+// instructions of 32 cycles per 32 x 192 task instead of 192 of 64 cycles, which leaves the kernel to the memory
+// system.  p.Wh then holds the weights split at pack time in fragment order: per row 64 halves hi, then 64 halves lo,
+// the halves of k-step s and lane half h being k = 16 s + 4 h + {0..3, 8..11} - the k values whose activations lane
+// (row, h) already holds in a[2s] and a[2s + 1], so the activations are split where they are.  A wave whose rows hold
+// a value of 2^15 or more, or nothing above 2^-8 (and not all zeros), multiplies with fp32 instructions from the fp32
+// weights in global memory instead.
+template <int NW4, bool HALF>  // NW4 = weight float4 loads a thread keeps in flight
 __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
     constexpr int LDK = 68;
     extern __shared__ __attribute__((aligned(16))) float Wsm[];  // [N][LDK] then the column-offset table
@@ -874,7 +941,7 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NW4; ++j) {
             const int q = min(q0 + j * (int)blockDim.x, total - 1);
-            w[j] = *reinterpret_cast<const float4*>(p.W + (size_t)q * 4);
+            w[j] = *reinterpret_cast<const float4*>((HALF ? p.Wh : p.W) + (size_t)q * 4);
         }
 #pragma unroll
         for (int j = 0; j < NW4; ++j) {
@@ -922,24 +989,27 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
     __syncthreads();
     if (m0 >= p.M) return;
 
+    // HALF: the wave's activations as fp16 halves, and whether they are in the range where that keeps 22 bits
+    f16x8 ah[HALF ? 4 : 1], al[HALF ? 4 : 1];
+    bool split_ok = false;
+    if constexpr (HALF) split_ok = split_frag64(a, ah, al);
+    const float out_scale = (HALF && split_ok) ? p.wscale : 1.0f;  // the split weights carry a power-of-two scale
+    const int ldw = p.ldw ? p.ldw : 64;
+
     for (int nt = nt_begin; nt < nt_begin + nt_per; ++nt) {
         // acc[r] = out[row m0 + (lane & 31)][column nt*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* Bs = Wsm + (nt * 32 + fr) * LDK + fh;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[kb].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[kb].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[kb].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
+        if constexpr (HALF) {
+            // (a wave out of range - rare - takes the fp32 instructions with the fp32 weights from global memory)
+            if (split_ok) acc = tile64_half(Wsm + (nt * 32 + fr) * LDK + fh, ah, al);
+            else acc = tile64_f32(p.W + (size_t)(nt * 32 + fr) * ldw + fh, a);
+        } else {
+            acc = tile64_f32(Wsm + (nt * 32 + fr) * LDK + fh, a);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(stage + fr * LDO + 8 * g + fh) =
-                make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                make_float4(acc[4 * g] * out_scale, acc[4 * g + 1] * out_scale, acc[4 * g + 2] * out_scale, acc[4 * g + 3] * out_scale);
         const int n = nt * 32 + oc4;
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + n);
         const unsigned long long co = coloff[n >> 2];
@@ -964,25 +1034,28 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
 // LayerNorm statistics come from the two lanes that share a row, and HBM sees o and x once and out once.
 // The three weight matrices sit in LDS ([64][68] each); the result goes through a wave-private LDS tile so that
 // rows are stored as contiguous 256-byte runs.
-__device__ __forceinline__ void gemm64_frag(const float* __restrict__ Ws, const float4 (&a)[8], float4 (&out)[8], int fr,
-                                            int fh) {
+// out = a W^T for a 64 x 64 matrix in LDS (HALF: its split form, with Wg the fp32 matrix in global memory for a wave
+// whose rows are out of the split's range, and `scale` undoing the weights' power-of-two scale).
+template <bool HALF>
+__device__ __forceinline__ void gemm64_frag(const float* __restrict__ Ws, const float* __restrict__ Wg, float scale,
+                                            const float4 (&a)[8], float4 (&out)[8], int fr, int fh) {
     constexpr int LDK = 68;
+    f16x8 ah[HALF ? 4 : 1], al[HALF ? 4 : 1];
+    bool split_ok = false;
+    if constexpr (HALF) split_ok = split_frag64(a, ah, al);
+    const float sc = (HALF && split_ok) ? scale : 1.0f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* Bs = Ws + (nt * 32 + fr) * LDK + fh;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[kb].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[kb].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[kb].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[kb].w, acc, 0, 0, 0);
+        if constexpr (HALF) {
+            if (split_ok) acc = tile64_half(Ws + (nt * 32 + fr) * LDK + fh, ah, al);
+            else acc = tile64_f32(Wg + (size_t)(nt * 32 + fr) * 64 + fh, a);
+        } else {
+            acc = tile64_f32(Ws + (nt * 32 + fr) * LDK + fh, a);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[4 * nt + q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q)
+            out[4 * nt + q] = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
     }
 }
 
@@ -990,14 +1063,16 @@ __device__ __forceinline__ void gemm64_frag(const float* __restrict__ Ws, const 
 // CT: the result is not stored but fed, still in registers, to the transposed convolution that consumes it
 //     (kernel 2, stride 2, 64 -> 64 channels = a 64 -> 256 GEMM whose column block q = (dy, dx) lands on output
 //     pixel (2y + dy, 2x + dx)): up[b][2y+dy][2x+dx][co] = sum_ci v[b][y][x][ci] * Wt[q*64 + co][ci] + bt[q*64 + co].
-template <bool FF, bool CT>
+// HALF: every product of the chain as a split-operand fp16 product (k_gemm_k64 HALF): `sp` holds the matrices split at pack
+// time in fragment order and their scales; each stage checks the range of its own operand rows.
+template <bool FF, bool CT, bool HALF>
 __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O, const float* __restrict__ X,
                                                      const float* __restrict__ Wo, const float* __restrict__ bo,
                                                      const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W2, const float* __restrict__ b2,
                                                      const float* __restrict__ Wt, const float* __restrict__ bt,
                                                      float* __restrict__ out, int M, int act, int ct_H, int ct_W,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, const Tail64Split sp) {
     constexpr int LDK = 68;
     constexpr int NW = FF ? 3 : 1;             // 64x64 matrices of the chain
     constexpr int WROWS = NW * 64 + (CT ? 256 : 0);
@@ -1031,10 +1106,10 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
                 const int q = min(q0 + j * (int)blockDim.x, total - 1);
                 const float* src;
                 int r = q;
-                if (q < 1024) src = Wo;
-                else if (FF && q < 2048) { src = W1; r = q - 1024; }
-                else if (FF && q < 3072) { src = W2; r = q - 2048; }
-                else { src = Wt; r = q - NW * 1024; }
+                if (q < 1024) src = HALF ? sp.wo : Wo;
+                else if (FF && q < 2048) { src = HALF ? sp.w1 : W1; r = q - 1024; }
+                else if (FF && q < 3072) { src = HALF ? sp.w2 : W2; r = q - 2048; }
+                else { src = HALF ? sp.wt : Wt; r = q - NW * 1024; }
                 w[j] = *reinterpret_cast<const float4*>(src + (size_t)r * 4);
             }
 #pragma unroll
@@ -1056,7 +1131,7 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
     if (m0 >= M) return;
 
     float4 att[8];
-    gemm64_frag(Ws, a, att, fr, fh);
+    gemm64_frag<HALF>(Ws, Wo, sp.so, a, att, fr, fh);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + 8 * u + fh);
@@ -1082,13 +1157,13 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
             a[u] = make_float4((att[u].x - mean) * rstd, (att[u].y - mean) * rstd, (att[u].z - mean) * rstd,
                                (att[u].w - mean) * rstd);
         float4 hid[8];
-        gemm64_frag(Ws + 64 * LDK, a, hid, fr, fh);
+        gemm64_frag<HALF>(Ws + 64 * LDK, W1, sp.s1, a, hid, fr, fh);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float4 bv = *reinterpret_cast<const float4*>(bias_s + 64 + 8 * u + fh);
             hid[u] = make_float4(gelu(hid[u].x + bv.x), gelu(hid[u].y + bv.y), gelu(hid[u].z + bv.z), gelu(hid[u].w + bv.w));
         }
-        gemm64_frag(Ws + 2 * 64 * LDK, hid, a, fr, fh);
+        gemm64_frag<HALF>(Ws + 2 * 64 * LDK, W2, sp.s2, hid, a, fr, fh);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float4 bv = *reinterpret_cast<const float4*>(bias_s + 128 + 8 * u + fh);
@@ -1125,23 +1200,22 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
     }
     const float* Wts = Ws + NW * 64 * LDK;
     const float* bts = bias_s + NW * 64;
+    f16x8 th[HALF ? 4 : 1], tl[HALF ? 4 : 1];
+    bool ct_ok = false;
+    if constexpr (HALF) ct_ok = split_frag64(att, th, tl);
+    const float ct_scale = (HALF && ct_ok) ? sp.st : 1.0f;
     for (int nt = 0; nt < 8; ++nt) {
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* Bs = Wts + (nt * 32 + fr) * LDK + fh;
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            const float4 bw = *reinterpret_cast<const float4*>(Bs + kb * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.x, att[kb].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.y, att[kb].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.z, att[kb].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.w, att[kb].w, acc, 0, 0, 0);
+        if constexpr (HALF) {
+            if (ct_ok) acc = tile64_half(Wts + (nt * 32 + fr) * LDK + fh, th, tl);
+            else acc = tile64_f32(Wt + (size_t)(nt * 32 + fr) * 64 + fh, att);
+        } else {
+            acc = tile64_f32(Wts + (nt * 32 + fr) * LDK + fh, att);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(stage + fr * LDO + 8 * g + fh) =
-                make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                make_float4(acc[4 * g] * ct_scale, acc[4 * g + 1] * ct_scale, acc[4 * g + 2] * ct_scale, acc[4 * g + 3] * ct_scale);
         const float4 bv = *reinterpret_cast<const float4*>(bts + nt * 32 + oc4);
         const int q = nt >> 1;
         if (part) {
@@ -1181,10 +1255,11 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
     }
 }
 
-template <bool FF, bool CT>
+template <bool FF, bool CT, bool HALF>
 static hipError_t launch_attn_tail64_t(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                                        const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                                       float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream) {
+                                       float* out, int M, int act, int ct_H, int ct_W, float* part, const Tail64Split& sp,
+                                       hipStream_t stream) {
     const int tasks = (M + 31) / 32;
     if (part && (!CT || M % 32 || (ct_H * ct_W) % 32)) return hipErrorInvalidValue;  // a slice = 32 rows of one image
     int waves = (FF && CT) ? 4 : 8;  // LDS budget; 4 also when there are few row tiles (fewer only stretch the staging)
@@ -1192,21 +1267,29 @@ static hipError_t launch_attn_tail64_t(const float* o, const float* x, const flo
     const int wrows = (FF ? 3 : 1) * 64 + (CT ? 256 : 0);
     const size_t lds = (size_t)(wrows * 68 + wrows + waves * 32 * (CT ? 36 : 68)) * sizeof(float);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_tail64<FF, CT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_tail64<FF, CT, HALF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_attn_tail64<FF, CT>), dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x, Wo,
-                       bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part);
+    hipLaunchKernelGGL((k_attn_tail64<FF, CT, HALF>), dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x,
+                       Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp);
     return hipGetLastError();
 }
 
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
-                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream) {
-    if (W1 && Wt) return launch_attn_tail64_t<true, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, stream);
-    if (W1) return launch_attn_tail64_t<true, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, nullptr, stream);
-    if (Wt) return launch_attn_tail64_t<false, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, stream);
+                              float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream,
+                              const Tail64Split* split) {
+    // the split-operand form needs the split copy of every matrix of the chain
+    const bool half = split && !g_igemm_fp32_products && split->wo && (!W1 || (split->w1 && split->w2)) && (!Wt || split->wt);
+    const Tail64Split sp = half ? *split : Tail64Split{};
+#define DANRA_TAIL64(FF_, CT_)                                                                                              \
+    (half ? launch_attn_tail64_t<FF_, CT_, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp, stream) \
+          : launch_attn_tail64_t<FF_, CT_, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp, stream))
+    if (W1 && Wt) return DANRA_TAIL64(true, true);
+    if (W1) { part = nullptr; return DANRA_TAIL64(true, false); }
+    if (Wt) return DANRA_TAIL64(false, true);
+#undef DANRA_TAIL64
     return hipErrorInvalidValue;  // the plain output projection goes through launch_igemm
 }
 
@@ -1299,12 +1382,18 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
     return hipGetLastError();
 }
 
-static int g_igemm_fp32_products = 0;
-void set_igemm_fp32_products(int on) { g_igemm_fp32_products = on ? 1 : 0; }
 
 // Whether launch_igemm runs these arguments in the split-operand fp16 form (the row-stationary K = 64 kernel never does).
+// Whether launch_igemm hands these arguments to the row-stationary K = 64 kernel.
+static bool takes_k64_path(const IGemmArgs& a) {
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    return a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
+           a.M >= 32768 && !a.tbias && !a.res && !a.out2;
+}
+
 bool igemm_uses_split(const IGemmArgs& a) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    if (takes_k64_path(a)) return a.half && a.Wh && !g_igemm_fp32_products && !a.ldw;
     return a.half && a.Wh && !g_igemm_fp32_products && a.a_mode != A_CONV1 && a.K % 64 == 0 && a.K >= 128 &&
            (a.a_mode != A_CONV || a.Cin % 64 == 0) && (ks == 1 || a.chunks_per_split % 2 == 0);
 }
@@ -1333,8 +1422,7 @@ hipError_t launch_igemm(const IGemmArgs& args, hipStream_t stream) {
     if (a.a_mode == A_CONV && !a.zeros) return hipErrorInvalidValue;
     if ((long long)a.M * a.N >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element indices within an output or slab
     if (a.out2 && (a.n_split <= 0 || a.n_split % BN || a.n_split >= a.N || a.st_mode != ST_ROW)) return hipErrorInvalidValue;
-    if (a.a_mode == A_GEMM && a.K == 64 && a.lda % 4 == 0 && ks == 1 && !a.force_bm && a.N <= 256 && a.N >= 128 &&
-        a.M >= 32768 && !a.tbias && !a.res && !a.out2) {
+    if (takes_k64_path(a)) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;
         const int tiles = (a.M + 31) / 32 * nsplit;
@@ -1346,17 +1434,22 @@ hipError_t launch_igemm(const IGemmArgs& args, hipStream_t stream) {
                            (size_t)a.N * sizeof(float) + (size_t)waves * 32 * 36 * sizeof(float);
         const int nw4 = (a.N * 16 + 64 * waves - 1) / (64 * waves);
         const dim3 grid((tiles + waves - 1) / waves), block(64 * waves);
-#define DANRA_LAUNCH_K64(NW4_)                                                                              \
+#define DANRA_LAUNCH_K64(NW4_, H_)                                                                          \
     do {                                                                                                    \
         if (lds > 48 * 1024) {                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_k64<NW4_>),             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_k64<NW4_, H_>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             if (e != hipSuccess) return e;                                                                  \
         }                                                                                                   \
-        DANRA_LAUNCH_KERNEL(k_gemm_k64<NW4_>, grid, block, lds, stream, b);                                  \
+        DANRA_LAUNCH_KERNEL((k_gemm_k64<NW4_, H_>), grid, block, lds, stream, b);                            \
     } while (0)
-        if (nw4 <= 4) DANRA_LAUNCH_K64(4);
-        else DANRA_LAUNCH_K64(16);
+        // (for K = 64 `Wh` is in the fragment order of this kernel: launch_split_weights with frag64)
+        const bool half64 = igemm_uses_split(a);
+        if (half64) {
+            if (nw4 <= 4) DANRA_LAUNCH_K64(4, true);
+            else DANRA_LAUNCH_K64(16, true);
+        } else if (nw4 <= 4) DANRA_LAUNCH_K64(4, false);
+        else DANRA_LAUNCH_K64(16, false);
 #undef DANRA_LAUNCH_K64
         return hipGetLastError();
     }

@@ -1003,22 +1003,31 @@ hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t strea
     return hipGetLastError();
 }
 
+// FRAG64 (rows of exactly 64 weights, the K = 64 row-stationary GEMM): the halves of a row in the order in which
+// that kernel's lanes hold the activations: slot (2 s + h) * 8 + e  <->  k = 16 s + 4 h + (e & 3) + 8 (e >> 2).
+template <bool FRAG64>
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, _Float16* __restrict__ out, size_t n,
                                                        float scale) {
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = w[i] * scale;  // exact: a power of two
         const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-        const size_t slot = (i >> 6) * 128 + (i & 63);
+        int col = (int)(i & 63);
+        if (FRAG64) {
+            const int st = col >> 4, in = col & 15;
+            col = (2 * st + ((in >> 2) & 1)) * 8 + (in & 3) + 4 * (in >> 3);
+        }
+        const size_t slot = (i >> 6) * 128 + col;
         out[slot] = (_Float16)h[0];
         out[slot + 64] = (_Float16)(v - (float)h[0]);
     }
 }
-hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream) {
+hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream, bool frag64) {
     if (n % 64) return hipErrorInvalidValue;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), n, scale);
+    if (frag64) hipLaunchKernelGGL(k_split_weights<true>, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), n, scale);
+    else hipLaunchKernelGGL(k_split_weights<false>, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), n, scale);
     return hipGetLastError();
 }
 

@@ -81,6 +81,9 @@ int main(int argc, char** argv) {
     float* Wh;
     CK(hipMalloc(&Wh, (size_t)16 << 20));
     CK(launch_split_weights(W, Wh, (size_t)4 << 20, 4096.f, 0));  // |w| < 1 here
+    float* Wh64;  // the same weights in the fragment order of the K = 64 row-stationary GEMM
+    CK(hipMalloc(&Wh64, (size_t)1 << 20));
+    CK(launch_split_weights(W, Wh64, (size_t)1 << 18, 4096.f, 0, true));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -102,6 +105,7 @@ int main(int argc, char** argv) {
             a.qkv_plane = (long long)a.M * s.Cin;
             a.ct_C = s.Cout / 4; a.ct_H = s.Hi; a.ct_W = s.Wi;
         }
+        if (a.K == 64) a.Wh = Wh64;
         const double flops = 2.0 * a.M * a.N * a.K;
         printf("%-26s M=%d N=%d K=%d  (%.2f GFLOP, %.1f us at 157 TF)\n", s.name, a.M, a.N, a.K, flops / 1e9, flops / 157.3e6);
         for (size_t ci = 0; ci < cfgs.size(); ++ci) {

@@ -457,6 +457,29 @@ def test_split_operand_forward_equals_fp32_products(cond64, golden, dev):
     assert not torch.equal(outs[0], outs[1]), "the switch changed nothing: the split-operand form did not run"
 
 
+def test_split_operand_k64_chain_falls_back_on_large_activations(cond64, dev):
+    """Batch 32 puts the last decoder block's attention tail and the final transposed convolution into one kernel whose
+    products are split-operand fp16 products; conditioning planes scaled by 3e5 drive the skip connection it adds - and
+    with it the operand of the transposed convolution - far beyond 2^15, so those waves must take the fp32 instructions.
+    Both settings of the library agree to the forward tolerance and stay finite."""
+    model, _, ops = cond64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 32, 64, seed=12).items()}
+    big = {k: (v * 3.0e5 if k in ("cond_img", "topo_cond") else v) for k, v in inp.items()}
+    t = torch.full((32,), 250, dtype=torch.long, device=dev)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            ops.lib.danra_set_fp32_products(mode)
+            with torch.no_grad():
+                outs[mode] = model(big["x"], t, big["y"], big["cond_img"], big["lsm_cond"], big["topo_cond"]).cpu()
+    finally:
+        ops.lib.danra_set_fp32_products(0)
+    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[1]).all()
+    assert rel_err(outs[0], outs[1]) < TOL_FWD
+    fmaps = model.hip_engine(dev).fmaps()
+    assert float(fmaps[0].abs().max()) > 32768.0, "the inputs did not drive the skip connection out of the fp16 range"
+
+
 def test_odd_batch_on_the_row_stationary_gemm(cond64, dev):
     """B = 33 at 64x64 puts 33792 tokens through the K=64 row-stationary GEMM (QKV at L=1024, final transposed
     convolution) with a partly empty last workgroup; every image must equal its own B = 1 evaluation."""

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--copies", action="store_true", help="attribute the aten::copy_ calls to python frames instead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     d = synthetic_inputs(args.batch, args.size, args.size, seed=42, conditional=True)
@@ -41,11 +42,26 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=args.copies) as prof:
         step()
         torch.cuda.synchronize()
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=60,
-                                                             max_shapes_column_width=70))
+    if not args.copies:
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=40,
+                                                                 max_name_column_width=60, max_shapes_column_width=70))
+        return
+    # who asks for the copies: aten::copy_ calls grouped by the innermost frames of this package / torch.nn on their stack
+    from collections import defaultdict
+    groups = defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if ev.name != "aten::copy_" or ev.device_time_total <= 0:
+            continue
+        frames = [f for f in (ev.stack or []) if "diffusionmodelscustom_amd" in f or "torch/nn/modules" in f or "autograd" in f]
+        key = " <- ".join(f.split("/")[-1][:70] for f in frames[:3]) or "(no python frame: backward engine)"
+        key += "   " + str(ev.input_shapes[:2])
+        groups[key][0] += 1
+        groups[key][1] += ev.device_time_total
+    for key, (n, us) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{us:9.1f} us  x{n:<4d} {key}")
 
 
 if __name__ == "__main__":
