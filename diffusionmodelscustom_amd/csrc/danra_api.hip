@@ -721,7 +721,7 @@ int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
 // in the same kernel as the output projection: ct_out receives [B][2*ct_H][2*ct_W][64] and `out` is not written.
 int run_attention(danra_handle_s* h, int index, const float* x, float* out, int B, int L, int relu, hipStream_t st,
                   const float* ct_w = nullptr, const float* ct_b = nullptr, float* ct_out = nullptr, int ct_H = 0,
-                  int ct_W = 0, const SplitW* ct_split = nullptr) {
+                  int ct_W = 0, const SplitW* ct_split = nullptr, bool ct_stats_only = false) {
     const AttnP& at = h->attn[index];
     const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
     Workspace& ws = h->ws;
@@ -758,8 +758,8 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         sp.w2 = at.s_ff2.wh; sp.s2 = at.s_ff2.inv_scale;
         if (ct_split) { sp.wt = ct_split->wh; sp.st = ct_split->inv_scale; }
         HIP_TRY(launch_attn_tail64(ws.obuf, x, at.w_out, at.b_out, at.w_ff1, at.b_ff1, at.w_ff2, at.b_ff2, ct_w, ct_b,
-                                   ct_w ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W,
-                                   ct_w ? ws.stats_part : nullptr, st, &sp));
+                                   (ct_w && !ct_stats_only) ? ct_out : out, B * L, relu ? ACT_RELU : ACT_NONE, ct_H, ct_W,
+                                   ct_w ? ws.stats_part : nullptr, st, &sp, ct_stats_only ? 1 : 0));
         return DANRA_OK;
     }
     float* attended = ff ? ws.qkv : out;
@@ -851,7 +851,7 @@ int run_time_mlp(danra_handle_s* h, const int64_t* t, SampleState* state, const 
 // next_wt/next_bt: apply the NEXT block's transposed convolution to this block's output (into ws.up, `out` unused).
 int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* skip, const float* tbias, float* out,
                       int B, int Hh, int Ww, hipStream_t st, bool up_ready = false, const float* next_wt = nullptr,
-                      const float* next_bt = nullptr, const SplitW* next_split = nullptr) {
+                      const float* next_bt = nullptr, const SplitW* next_split = nullptr, bool next_stats_only = false) {
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
@@ -869,13 +869,22 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     HIP_TRY(launch_in_stats(slabs.count ? ws.partial : ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B,
                             H2 * W2, d.Cout, st, ws.pre, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width,
                             slabs.count ? &slabs : nullptr));
-    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2, next_split));
+    RC_TRY(run_attention(h, 5 + k, ws.pre, out, B, H2 * W2, 1, st, next_wt, next_bt, ws.up, H2, W2, next_split,
+                         next_stats_only));
     return DANRA_OK;
 }
 
+// up_ready: ws.up holds the transposed convolution and ws.stats_part its statistics in slices (the previous block's
+// attention tail applied it); stats_only: only the statistics are there and `in` is that block's output - the
+// transposed convolution is rebuilt inside the convolution kernel and the 64-channel tensor at full resolution never exists.
 int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, int Hh, int Ww, hipStream_t st,
-                    bool up_ready = false) {
+                    bool up_ready = false, bool stats_only = false) {
     Workspace& ws = h->ws;
+    if (stats_only) {
+        HIP_TRY(launch_final_up_conv(in, h->final_wt, h->final_bt, h->final_conv.w, h->final_conv.bias, eps_nchw, B, Hh, Ww,
+                                     h->cfg.out_channels, ws.stats_part, Hh * Ww / 8, 32, st));
+        return DANRA_OK;
+    }
     if (!up_ready) {
         RC_TRY(run_convT(h, h->final_wt, h->final_bt, 64, in, ws.up, B, Hh, Ww, st, &h->final_s_wt));
         HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, 4 * Hh * Ww, 64, st));
@@ -923,7 +932,7 @@ int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleStat
     // A 64-channel block's output feeds only the next block's transposed convolution, which is row-local like the
     // block's own output projection: the two run as one kernel and the block's output never reaches memory.
     const float* din = ws.fmap[4];
-    bool up_ready = false;
+    bool up_ready = false, stats_only = false;
     for (int k = 0; k < 4; ++k) {
         float* dout = (k & 1) ? ws.outB : ws.outA;
         const float *next_wt = nullptr, *next_bt = nullptr;
@@ -933,14 +942,16 @@ int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleStat
             next_wt = (k < 3) ? h->dec[k + 1].wt : h->final_wt;
             next_bt = (k < 3) ? h->dec[k + 1].bt : h->final_bt;
             next_split = (k < 3) ? &h->dec[k + 1].s_wt : &h->final_s_wt;
+            // the final block rebuilds its transposed convolution from this block's output: only the statistics are formed here
+            stats_only = (k == 3) && final_up_conv_supported(2 * Hc, 2 * Wc);
         }
         RC_TRY(run_decoder_block(h, k, din, ws.fmap[3 - k], ws.tbias, dout, B, Hc, Wc, st, up_ready, next_wt, next_bt,
-                                 next_split));
+                                 next_split, stats_only));
         up_ready = next_wt != nullptr;
         din = dout;
         Hc *= 2; Wc *= 2;
     }
-    RC_TRY(run_final_block(h, din, eps, B, Hc, Wc, st, up_ready));
+    RC_TRY(run_final_block(h, din, eps, B, Hc, Wc, st, up_ready, stats_only));
     return DANRA_OK;
 }
 

@@ -90,6 +90,8 @@ bool igemm_uses_split(const IGemmArgs& a);
 // With Wt and `part` (M and ct_H*ct_W multiples of 32) the kernel also leaves the InstanceNorm statistics of its output in
 // slices: part[image][S = ct_H*ct_W/8][{mean, centred sum of squares}][64], 32 samples per slice, for
 // launch_in_stats_from_slices.  At least one of W1 and Wt must be given.
+// ct_stats_only (with Wt and `part`): the transposed convolution is formed for its statistics only and `out` receives
+// the block's own output rows [M][64] - for a consumer that rebuilds the transposed convolution (launch_final_up_conv).
 // `split` (optional): the matrices split in fp16 halves in fragment order (launch_split_weights with frag64) and the
 // inverse of each one's power-of-two scale; the chain then multiplies on the fp16 matrix cores (fp32 results, fp32
 // instructions for rows out of the split's range).
@@ -100,7 +102,7 @@ struct Tail64Split {
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
                               float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream,
-                              const Tail64Split* split = nullptr);
+                              const Tail64Split* split = nullptr, int ct_stats_only = 0);
 
 // One input plane's share of the 8x8 stride-2 pad-3 stem: out = conv(x; Wt[64][8x8], row stride ldw) [+ res] [+ tbias[b]],
 // x: [B][H][W], out/res: [B][H/2][W/2][64]; H and W multiples of 16.
@@ -194,6 +196,13 @@ bool final_conv_merges_slices(int H, int W, int Cin);
 hipError_t launch_final_conv(const float* x, const float* mean, const float* rstd, const float* w, const float* bias,
                              float* out, int B, int H, int W, int Cin, int Cout, hipStream_t stream,
                              const float* part = nullptr, int S = 0, int count = 0);
+// The final block from its input hin [B][Hh][Ww][64] without the upsampled tensor: transposed convolution (Wt [256][64],
+// bt [256] as launch_pack_convT lays them out) + InstanceNorm (statistics of the transposed convolution's output in
+// slices, part[image][S][{mean, m2}][64], `count` samples each) + 3x3 convolution w [Cout][9][64] -> out [B][Cout][2Hh][2Ww].
+bool final_up_conv_supported(int Hh, int Ww);
+hipError_t launch_final_up_conv(const float* hin, const float* Wt, const float* bt, const float* w, const float* bias,
+                                float* out, int B, int Hh, int Ww, int Cout, const float* part, int S, int count,
+                                hipStream_t stream);
 hipError_t launch_ddpm_update(float* x, const float* eps, const float* noise, float c1, float c2, float c3,
                               size_t n, int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
 // noisy = sqrt(alpha_hat[t_b]) * x + sqrt(1 - alpha_hat[t_b]) * z; z read from `noise` or drawn (and written there)

@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
                                                      const float* __restrict__ W2, const float* __restrict__ b2,
                                                      const float* __restrict__ Wt, const float* __restrict__ bt,
                                                      float* __restrict__ out, int M, int act, int ct_H, int ct_W,
-                                                     float* __restrict__ part, const Tail64Split sp) {
+                                                     float* __restrict__ part, const Tail64Split sp, int ct_stats_only) {
     constexpr int LDK = 68;
     constexpr int NW = FF ? 3 : 1;             // 64x64 matrices of the chain
     constexpr int WROWS = NW * 64 + (CT ? 256 : 0);
@@ -1246,11 +1246,26 @@ __global__ __launch_bounds__(512) void k_attn_tail64(const float* __restrict__ O
             }
         }
         const unsigned long long co = ((unsigned long long)(q >> 1) * 2 * ct_W + (q & 1)) * 64 + (nt & 1) * 32 + oc4;
+        if (ct_stats_only) continue;  // the consumer rebuilds this tile from the block's output (below) and the statistics
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (m0 + orow + 8 * j < M) *reinterpret_cast<float4*>(out + rbase[j] + co) = v;
+        }
+    }
+    if (ct_stats_only) {
+        // the block's own output rows [M][64] instead of the transposed convolution's: two passes of 32 columns through
+        // the wave's tile, 8 consecutive lanes store 128 contiguous bytes of a row
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stage + fr * LDO + 8 * u + fh) = att[4 * half + u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m0 + orow + 8 * j < M)
+                    *reinterpret_cast<float4*>(out + (size_t)(m0 + orow + 8 * j) * 64 + 32 * half + oc4) =
+                        *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
         }
     }
 }
@@ -1259,9 +1274,10 @@ template <bool FF, bool CT, bool HALF>
 static hipError_t launch_attn_tail64_t(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                                        const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
                                        float* out, int M, int act, int ct_H, int ct_W, float* part, const Tail64Split& sp,
-                                       hipStream_t stream) {
+                                       int ct_stats_only, hipStream_t stream) {
     const int tasks = (M + 31) / 32;
     if (part && (!CT || M % 32 || (ct_H * ct_W) % 32)) return hipErrorInvalidValue;  // a slice = 32 rows of one image
+    if (ct_stats_only && !part) return hipErrorInvalidValue;
     int waves = (FF && CT) ? 4 : 8;  // LDS budget; 4 also when there are few row tiles (fewer only stretch the staging)
     while (waves > 4 && tasks < 128 * waves) waves /= 2;
     const int wrows = (FF ? 3 : 1) * 64 + (CT ? 256 : 0);
@@ -1272,22 +1288,24 @@ static hipError_t launch_attn_tail64_t(const float* o, const float* x, const flo
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_attn_tail64<FF, CT, HALF>), dim3((tasks + waves - 1) / waves), dim3(64 * waves), lds, stream, o, x,
-                       Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp);
+                       Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp, ct_stats_only);
     return hipGetLastError();
 }
 
 hipError_t launch_attn_tail64(const float* o, const float* x, const float* Wo, const float* bo, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* Wt, const float* bt,
                               float* out, int M, int act, int ct_H, int ct_W, float* part, hipStream_t stream,
-                              const Tail64Split* split) {
+                              const Tail64Split* split, int ct_stats_only) {
     // the split-operand form needs the split copy of every matrix of the chain
     const bool half = split && !g_igemm_fp32_products && split->wo && (!W1 || (split->w1 && split->w2)) && (!Wt || split->wt);
     const Tail64Split sp = half ? *split : Tail64Split{};
 #define DANRA_TAIL64(FF_, CT_)                                                                                              \
-    (half ? launch_attn_tail64_t<FF_, CT_, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp, stream) \
-          : launch_attn_tail64_t<FF_, CT_, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp, stream))
+    (half ? launch_attn_tail64_t<FF_, CT_, true>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp,       \
+                                                 ct_stats_only, stream)                                                       \
+          : launch_attn_tail64_t<FF_, CT_, false>(o, x, Wo, bo, W1, b1, W2, b2, Wt, bt, out, M, act, ct_H, ct_W, part, sp,      \
+                                                  ct_stats_only, stream))
     if (W1 && Wt) return DANRA_TAIL64(true, true);
-    if (W1) { part = nullptr; return DANRA_TAIL64(true, false); }
+    if (W1) { part = nullptr; ct_stats_only = 0; return DANRA_TAIL64(true, false); }
     if (Wt) return DANRA_TAIL64(false, true);
 #undef DANRA_TAIL64
     return hipErrorInvalidValue;  // the plain output projection goes through launch_igemm

@@ -653,6 +653,221 @@ __global__ __launch_bounds__(256) void k_final_conv_mfma(const float* __restrict
     }
 }
 
+// The final block without its 64 x 64 x 64-channel tensor: transposed convolution (kernel 2, stride 2, 64 -> 64),
+// InstanceNorm and the 3x3 convolution to Cout channels, from the block's INPUT hin [B][Hh][Ww][64].
+// The upsampled pixel q = (2y + dy, 2x + dx) is u(q)[c] = sum_k Wt[(dy, dx)][c][k] hin(y, x)[k] + bt[c], so what
+// k_final_conv_mfma calls G - the nine tap sums of a pixel - is linear in hin of the PARENT pixel:
+//     G[q][tap] = hin(parent) . GW[(dy, dx)][tap] + const[tap],  GW[par][tap][k] = sum_c w[tap][c] rstd[c] Wt[par][c][k].
+// A workgroup (R output rows of one image) forms GW for its image (36 vectors of 64: one small matrix product per
+// parity, the wave that owns the parity reads Wt straight from memory), then G for its strip as hin [pixels][64] x
+// GW^T [64][36] on the matrix cores - four upsampled pixels x nine taps per parent pixel - and sums taps as before.
+// The statistics of u arrive in slices from the kernel that would have stored it (k_attn_tail64 in its
+// statistics-only form).  Reads 16 B/parent-pixel-channel once instead of writing and re-reading four times as much.
+__global__ __launch_bounds__(256) void k_final_up_conv_mfma(const float* __restrict__ hin, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bt, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int Hh, int Ww, int Cout, int R, const float* __restrict__ part,
+                                                            int S, int count) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int LDG = 68;       // row pitch of GW in LDS (conflict-free 16-byte fragment reads)
+    const int H = 2 * Hh, W = 2 * Ww;
+    const int P = (R + 2) * W;    // upsampled pixels of the strip incl. halo rows
+    const int PS = P + 1;
+    float* Gs = sm;               // [9][PS]
+    float* gw = sm + 9 * PS;      // [48][LDG]: row n = parity * 9 + tap (rows 36..47 zero)
+    float* wcs = gw + 48 * LDG;   // [16]
+    float* stat = wcs + 16;       // [2][64] mean, 1/std of u for this image
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * R;  // first output row (even)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const float* hb = hin + (size_t)b * Hh * Ww * 64;
+    // A workgroup is alone on its CU and every phase below starts with a trip to memory, so the loads that depend on
+    // nothing are issued first: the activations of the wave's first tiles and its parity's slice of Wt.
+    const int pr0 = (y0 >> 1) - 1, prows = R / 2 + 2;
+    const int ntiles = prows * Ww / 16;
+    constexpr int TPW = 6;  // tiles of a wave whose activations are loaded together
+    float4 afs[TPW][4];
+    auto load_tiles = [&](int tb) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(tb + wave + 4 * i, ntiles - 1);
+            const int ry = (t * 16) / Ww;
+            const int py = min(max(pr0 + ry, 0), Hh - 1);
+            const float* src = hb + ((size_t)py * Ww + (t * 16 - ry * Ww) + lq) * 64 + 4 * g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) afs[i][s] = *reinterpret_cast<const float4*>(src + 16 * s);
+        }
+    };
+    load_tiles(0);
+    // Wt[wave * 64 + c][k] as B fragments of D[tap][k] = sum_c wr[tap][c] Wt[c][k]: lane (k = 16 nt + lq, g), c = 16 s + 4 g + r
+    float bq[4][16];
+    {
+        const float* wtp = Wt + (size_t)wave * 64 * 64;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bq[nt][4 * s + r] = wtp[(size_t)(16 * s + 4 * g + r) * 64 + 16 * nt + lq];
+    }
+    {   // merge the statistics slices (the arithmetic of k_in_stats_merge64; 32 slices of a thread in flight together)
+        float* red = Gs;  // [4][64]
+        const int c = tid & 63, w4 = tid >> 6;
+        const float* src = part + (size_t)b * S * 128 + c;
+        float msum = 0.f, m2 = 0.f;
+        for (int s0 = w4; s0 < S; s0 += 128) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) msum += (s0 + 4 * u < S) ? v[u] : 0.f;
+        }
+        red[w4 * 64 + c] = msum;
+        __syncthreads();
+        const float mu = (red[c] + red[64 + c] + red[128 + c] + red[192 + c]) / (float)S;
+        __syncthreads();
+        for (int s0 = w4; s0 < S; s0 += 64) {
+            float v[16], q[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                v[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128];
+                q[u] = src[(size_t)min(s0 + 4 * u, S - 1) * 128 + 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float d = v[u] - mu;
+                m2 += (s0 + 4 * u < S) ? q[u] + (float)count * d * d : 0.f;
+            }
+        }
+        red[w4 * 64 + c] = m2;
+        __syncthreads();
+        if (w4 == 0) {
+            const float tot = red[c] + red[64 + c] + red[128 + c] + red[192 + c];
+            stat[c] = mu;
+            stat[64 + c] = 1.0f / sqrtf(tot / ((float)S * (float)count) + 1e-5f);
+        }
+        __syncthreads();
+    }
+    for (int q = tid; q < 12 * LDG; q += 256) gw[36 * LDG + q] = 0.f;  // the padding rows of the last 16-column tile
+    for (int co = 0; co < Cout; ++co) {
+        // wr[tap][c] = w[co][tap][c] * rstd[c] as matrix fragments: lane (tap, g) holds c = 16 s + 4 g + r
+        float4 wf[4];
+        float wc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = 16 * s + 4 * g;
+            const float4 wv = *reinterpret_cast<const float4*>(w + ((size_t)co * 9 + min(lq, 8)) * 64 + c);
+            const float4 rs = *reinterpret_cast<const float4*>(stat + 64 + c);
+            const float4 mu = *reinterpret_cast<const float4*>(stat + c);
+            const float4 bb = *reinterpret_cast<const float4*>(bt + c);
+            const float keep = lq < 9 ? 1.f : 0.f;
+            wf[s] = make_float4(wv.x * rs.x * keep, wv.y * rs.y * keep, wv.z * rs.z * keep, wv.w * rs.w * keep);
+            // what the normalisation subtracts, less the transposed convolution's bias
+            wc += (wf[s].x * (mu.x - bb.x) + wf[s].y * (mu.y - bb.y)) + (wf[s].z * (mu.z - bb.z) + wf[s].w * (mu.w - bb.w));
+        }
+        wc += __shfl_xor(wc, 16);
+        wc += __shfl_xor(wc, 32);
+        if (wave == 0 && g == 0) wcs[lq] = wc;
+        // ---- GW for parity `wave`, four 16-column tiles of k
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4m acc = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, bq[nt][4 * s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, bq[nt][4 * s + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, bq[nt][4 * s + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, bq[nt][4 * s + 3], acc, 0, 0, 0);
+            }
+            // C/D layout: column = k = 16 nt + lq, row = tap = 4 g + reg
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < 9) gw[(wave * 9 + 4 * g + r) * LDG + 16 * nt + lq] = acc[r];
+        }
+        __syncthreads();
+        // ---- G of the strip: parent rows (y0 - 1) >> 1 .. (y0 + R) >> 1, sixteen parent pixels per tile
+        for (int tb = 0; tb < ntiles; tb += 4 * TPW) {
+            if (tb > 0 || co > 0) load_tiles(tb);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int t = tb + wave + 4 * i;
+                if (t >= ntiles) continue;
+                const int p0 = t * 16;
+                const int ry = p0 / Ww;
+                const int py = pr0 + ry;
+                if (py < 0 || py >= Hh) continue;  // wave-uniform
+                const int px0 = p0 - ry * Ww;
+                const float4 (&af)[4] = afs[i];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4m acc = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float4 bf = *reinterpret_cast<const float4*>(gw + (16 * j + lq) * LDG + 16 * s + 4 * g);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].x, bf.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].y, bf.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].z, bf.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].w, bf.w, acc, 0, 0, 0);
+                    }
+                    // column n = 16 j + lq = parity * 9 + tap, row = parent pixel 4 g + reg of the tile
+                    const int n = 16 * j + lq;
+                    if (n < 36) {
+                        const int par = n / 9, tap = n - par * 9;
+                        const int uy = 2 * py + (par >> 1) - (y0 - 1);  // row within the strip (0 = halo row y0 - 1)
+                        if (uy >= 0 && uy < R + 2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Gs[tap * PS + uy * W + 2 * (px0 + 4 * g + r) + (par & 1)] = acc[r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every output pixel sums its nine in-bounds taps of G minus the folded mean term
+        const float bco = bias ? bias[co] : 0.f;
+        for (int q = tid; q < R * W; q += 256) {
+            const int ry = q / W, ox = q - ry * W;
+            const int oy = y0 + ry;
+            float acc = bco;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                const int iy = oy + dy - 1, ix = ox + dx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc += Gs[tap * PS + (ry + dy) * W + ix] - wcs[tap];
+            }
+            out[((size_t)b * Cout + co) * H * W + (size_t)oy * W + ox] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+static int final_up_conv_rows(int Hh, int Ww) {
+    // output rows per workgroup: even, dividing the output height, the strip's G planes within 60 KB of LDS
+    if (Ww % 16 || Hh < 2) return 0;
+    // measured at 64 x 64 outputs, batch 64: 16 rows 23 us, 8 rows 26 us, 4 rows 42 us (the per-workgroup phases dominate)
+    for (int R = 16; R >= 2; R /= 2)
+        if ((2 * Hh) % R == 0 && 9 * ((size_t)(R + 2) * 2 * Ww + 1) * sizeof(float) <= 60 * 1024) return R;
+    return 0;
+}
+bool final_up_conv_supported(int Hh, int Ww) { return final_up_conv_rows(Hh, Ww) != 0 && (Hh * Ww) % 32 == 0; }
+
+hipError_t launch_final_up_conv(const float* hin, const float* Wt, const float* bt, const float* w, const float* bias,
+                                float* out, int B, int Hh, int Ww, int Cout, const float* part, int S, int count,
+                                hipStream_t stream) {
+    const int R = final_up_conv_rows(Hh, Ww);
+    if (!R || !part) return hipErrorInvalidValue;
+    const size_t lds = (9 * ((size_t)(R + 2) * 2 * Ww + 1) + 48 * 68 + 16 + 128) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_final_up_conv_mfma),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_final_up_conv_mfma, dim3(2 * Hh / R, B), dim3(256), lds, stream, hin, Wt, bt, w, bias, out, Hh, Ww,
+                       Cout, R, part, S, count);
+    return hipGetLastError();
+}
+
 bool final_conv_merges_slices(int H, int W, int Cin) {
     if (Cin != 64 || W % 16) return false;
     int R = 8;

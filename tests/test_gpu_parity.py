@@ -670,6 +670,32 @@ def test_other_geometries(dev, layers, dim, out_ch):
     assert rel_err(got.cpu(), want) < TOL_FWD
 
 
+def test_fused_final_block_with_three_output_channels(dev):
+    """From 32768 token rows on (batch 32 at 64x64) the last decoder block keeps its output at 32x32 and the final 3x3
+    convolution rebuilds the transposed convolution in front of it from those rows.  Three output channels make the
+    kernel's loop over output channels run more than once; images equal their B = 1 evaluation (which takes the
+    unfused kernels) and one of them the restatement."""
+    from diffusionmodelscustom_amd import Decoder, DiffusionNet, Encoder
+    from diffusionmodelscustom_amd.synthetic import fill_state_dict_
+    enc = Encoder(1, 256, lsm_tensor=torch.zeros(1, 64, 64), topo_tensor=torch.zeros(1, 64, 64), cond_on_img=True,
+                  cond_img_dim=(1, 64, 64), block_layers=[2, 2, 2, 2], num_classes=4)
+    model = fill_state_dict_(DiffusionNet(enc, Decoder(512, 3, 256, 64)), 11).eval()
+    sd = state_dict_cpu(model)
+    model = model.to(dev)
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", 32, 64, seed=23).items()}
+    t = torch.arange(32, device=dev) * 31 + 2
+    with torch.no_grad():
+        full = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"])
+        assert full.shape == (32, 3, 64, 64)
+        for i in (0, 13, 31):
+            one = model(inp["x"][i:i + 1], t[i:i + 1], inp["y"][i:i + 1], inp["cond_img"][i:i + 1],
+                        inp["lsm_cond"][i:i + 1], inp["topo_cond"][i:i + 1])
+            assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
+        want = cpu_ref.unet_forward(sd, inp["x"][31:32].cpu(), t[31:32].cpu(), inp["y"][31:32].cpu(),
+                                    inp["cond_img"][31:32].cpu(), inp["lsm_cond"][31:32].cpu(), inp["topo_cond"][31:32].cpu())
+    assert rel_err(full[31:32].cpu(), want) < TOL_FWD
+
+
 def test_oversized_call_is_refused_before_any_allocation(cond64, dev):
     """B*H*W >= 2^24 pixels would overflow the kernels' 32-bit offsets: the call is refused with a message."""
     model, _, _ = cond64
