@@ -55,12 +55,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //
 // QKH: S^T = K Q^T on the fp16 matrix cores as well.  Both operands are split as x = h + 2^-11 l, h = fp16(x),
 // l = fp16(2^11 (x - h)) (Q after its multiplication by hd^-1/2 log2 e); the three products that matter are two
-// 32-deep instructions per 16 keys and query tile with NO arithmetic in the loop (K is split by the staging threads,
-// Q once per kernel):  [Kh | Kl] [Qh | 2^-11 Qh]^T  +  [2^-11 Kh | 0] [Ql | 0]^T  =  Kh Qh + 2^-11 (Kl Qh + Kh Ql).
+// 32-deep instructions per 16 keys and query tile that read the SAME K fragment, with NO arithmetic in the loop (K is
+// split by the staging threads, Q once per kernel):  [Kh | Kl] [Qh | 2^-11 Qh]^T  +  [Kh | Kl] [2^-11 Ql | 0]^T  =
+// Kh Qh + 2^-11 (Kl Qh + Kh Ql).  Every 2^-11 factor sits on the Q side, so a key row of the LDS tile is just its 32
+// halves (64 bytes: a quarter of the tile's reads and half of its bytes against a tile that also carries 2^-11 Kh).
 // The 2^-11 copies may be fp16 subnormals (quantum 2^-24), which bounds the absolute score error by
-// 16 * 2^-26 (max|K| + max|Q'|) on top of 2^-22 sum|k q'| for the dropped Kl Ql term.  The softmax reference still
+// 16 * 2^-23 max|K| on top of 2^-22 sum|k q'| for the dropped Kl Ql term.  The softmax reference still
 // enters as the C operand of the first product.  The range flag covers |K| and |Q'| < 2^15 as it does V.
-static constexpr int KHROW = 72;  // halves per key row of the fp16 K tile: [h 16 | l 16 | 2^-11 h 16 | zero 16] + 8 of padding
+// Row layout: four groups of [h 4 | l 4] halves (columns 4g .. 4g + 3 of both parts are the eight k-slots of lane group g),
+// so a staging thread writes its four columns as one 16-byte store and the fragment reads of a wave are 1 KB in a line.
+static constexpr int KHROW = 32;  // halves per key row of the fp16 K tile
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
@@ -120,23 +124,23 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         for (int t = 0; t < QT; ++t) qf[t] = load_qf(t);
     }
 
-    // fp16 form of the Q fragments: lane (q, g) holds columns 8 (g & 1) ... + 7; k-groups 0, 1 carry [Qh], [Ql],
-    // k-groups 2, 3 carry [2^-11 Qh], [0] (see QKH above)
+    // fp16 form of the Q fragments: lane (q, g) holds columns 4g ... 4g + 3.  First product: [Qh | 2^-11 Qh] against the
+    // key row's [Kh | Kl]; second product: [2^-11 Ql | 0] = [fp16(x - h) | 0] against the same row (see QKH above)
     f16x8 qb1[QT], qb2[QT];
     bool q_bounded = true;
     if (QKH) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float* qp = Qb + (size_t)(q0 + t * 16 + lq) * 16 + 8 * (g & 1);
-            const float4 qa = *reinterpret_cast<const float4*>(qp), qc = *reinterpret_cast<const float4*>(qp + 4);
-            const float qq[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
+            const float4 qa = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+            const float qq[4] = {qa.x, qa.y, qa.z, qa.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const float x = qq[i] * scale_log2e;
                 const _Float16 hi = (_Float16)x;
-                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
-                qb1[t][i] = (g < 2) ? hi : (_Float16)((float)hi * 0.00048828125f);
-                qb2[t][i] = (g < 2) ? lo : (_Float16)0.f;
+                qb1[t][i] = hi;
+                qb1[t][4 + i] = (_Float16)((float)hi * 0.00048828125f);
+                qb2[t][i] = (_Float16)(x - (float)hi);
+                qb2[t][4 + i] = (_Float16)0.f;
                 q_bounded = q_bounded && (fabsf(x) < 32768.f);
             }
         }
@@ -196,16 +200,11 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
             *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
         }
         if (QKH) {
-            unsigned h[2], l[2], sh[2];
+            unsigned h[2], l[2];
             split_scaled(kreg.x, kreg.y, h[0], l[0]);
             split_scaled(kreg.z, kreg.w, h[1], l[1]);
-            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            const f16x2 tiny2 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) sh[c] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, h[c]) * tiny2);  // 2^-11 h (v_pk_mul_f16)
-            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + sc4]) = u32x2{h[0], h[1]};
-            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 16 + sc4]) = u32x2{l[0], l[1]};
-            *reinterpret_cast<u32x2*>(&Kh[buf][srow * KHROW + 32 + sc4]) = u32x2{sh[0], sh[1]};
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4*>(&Kh[buf][srow * KHROW + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
             const float kmax = fmaxf(max3f(fabsf(kreg.x), fabsf(kreg.y), fabsf(kreg.z)), fabsf(kreg.w));
             if (!(kmax < 32768.f)) vbig_s[buf] = 1;
         }
@@ -223,11 +222,6 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     };
     if (PVH) {
         if (tid < 2) vbig_s[tid] = 0;
-        if (QKH) {  // the zero quarter of every key row, both buffers (the staging never touches it)
-            const f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            *reinterpret_cast<f16x4*>(&Kh[0][srow * KHROW + 48 + sc4]) = z;
-            *reinterpret_cast<f16x4*>(&Kh[1][srow * KHROW + 48 + sc4]) = z;
-        }
         __syncthreads();
     }
     stage(0);
@@ -258,13 +252,11 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (QKH && FAST) {
-                    const _Float16* krow = &Kh[buf][((2 * hf + j) * 16 + lq) * KHROW + 8 * g];
-                    const f16x8 ka1 = *reinterpret_cast<const f16x8*>(krow);
-                    const f16x8 ka2 = *reinterpret_cast<const f16x8*>(krow + 32);
+                    const f16x8 ka = *reinterpret_cast<const f16x8*>(&Kh[buf][((2 * hf + j) * 16 + lq) * KHROW + 8 * g]);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, qb1[t], negm[t], 0, 0, 0);
-                        s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka2, qb2[t], a, 0, 0, 0);
+                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb1[t], negm[t], 0, 0, 0);
+                        s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb2[t], a, 0, 0, 0);
                     }
                     continue;
                 }
