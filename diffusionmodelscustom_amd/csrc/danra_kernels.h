@@ -234,6 +234,17 @@ bool linear_wgrad_supported(int M, int N, int K);
 hipError_t launch_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* workspace,
                                hipStream_t stream);
 
+// 3x3 stride-1 padding-1 convolution of the training step on NCHW fp32 tensors with [Cout][Cin][3][3] weights
+// (kernels_conv_train.hip): forward, data gradient (dgrad = true: in = dy, out = dx) and weight gradient.  workspace:
+// conv3x3_train_workspace_floats(...) floats (slabs of the sums that run over workgroups).
+bool conv3x3_train_supported(int B, int Cin, int Cout, int H, int W);
+size_t conv3x3_train_workspace_floats(int B, int Cin, int Cout, int H, int W);
+hipError_t launch_conv3x3_train(bool dgrad, const float* in, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
+                                float* workspace, hipStream_t stream);
+hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                      float* workspace, hipStream_t stream);
+__global__ void k_sum_slices(const float* __restrict__ part, float* __restrict__ out, int count4, int slices);
+
 // ---------------------------------------------------------------- weight packing
 // max |w| over n floats -> *out (one float; not atomic across launches: one launch per destination)
 hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t stream);

@@ -1,0 +1,421 @@
+// Training-step kernels for the 3x3, stride-1, padding-1 convolutions of the network (the sixteen BasicBlock
+// convolutions of stride 1 and the decoder blocks' convolutions), on contiguous NCHW fp32 tensors and the
+// [Cout][Cin][3][3] weights exactly as the differentiable torch composition holds them: no layout conversion and no
+// weight repack around a call.  Three products, all on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains):
+//
+//   forward        y[b][co][p]  = sum_{ci,tap} w[co][ci][tap] x[b][ci][p + tap]
+//   data gradient  dx[b][ci][p] = sum_{co,tap} w[co][ci][8 - tap] dy[b][co][p + tap]     (same kernel, weights re-indexed
+//                                                                                          while they are staged)
+//   weight grad.   dw[co][ci][tap] = sum_{b,p} dy[b][co][p] x[b][ci][p + tap]
+//
+// Geometry shared by the three: a "pixel tile" is 64 consecutive pixels in (image, row, column) order: 64 / W whole
+// rows of one image when the image has at least 64 pixels, else 64 / (H W) whole images.  The input channels a
+// workgroup needs for its tile are staged in LDS as a WINDOW with a zero halo: per channel, per image of the tile,
+// (rows + 2) x (W + 2) floats, so that tap (ty, tx) of a pixel is the window value at a fixed offset from the pixel's
+// own position and no bounds check exists in the product loop.
+//
+// Weights are the MFMA A operand (rows = output channels), pixels the B operand: the 32x32 accumulator of a lane holds
+// 16 output channels of ONE pixel, and for a fixed register the 32 lanes of a half-wave are 32 consecutive pixels: NCHW
+// stores are 128-byte runs.  Sums that run over workgroups (split reduction channels, pixel slices of the weight
+// gradient) go to slabs that k_sum_slices adds in slab order: nothing is accumulated with atomics, results are
+// bit-reproducible.
+#include "danra_kernels.h"
+
+namespace danra {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int CT_PX = 64;    // pixels per tile
+constexpr int CT_KC = 8;     // reduction channels per chunk (forward / data gradient)
+constexpr int CT_NO = 32;    // output channels per workgroup (forward / data gradient)
+constexpr int CT_LDW = 73;   // LDS row of the staged weights: 8 channels x 9 taps + 1 (odd: conflict-free column reads)
+constexpr int CT_MAXWIN = 256;  // largest window per channel: 16 images of 2x2 -> 16 x 4 x 4
+
+struct ConvTrainGeom {
+    int B, H, W, logW;
+    int NI, RH;        // images and rows per image of a pixel tile
+    int WIN;           // window floats per channel = NI * (RH + 2) * (W + 2)
+    int tiles_per_img; // NI == 1: H / RH
+    int n_tiles;
+    int M;             // B * H * W
+};
+
+bool make_geom(int B, int H, int W, ConvTrainGeom& g) {
+    if (B <= 0 || H <= 0 || W < 2 || W > 64 || (W & (W - 1)) || CT_PX % W) return false;
+    g.B = B; g.H = H; g.W = W;
+    g.logW = 0;
+    while ((1 << g.logW) < W) ++g.logW;
+    if (H * W >= CT_PX) {
+        g.NI = 1;
+        g.RH = CT_PX / W;
+        if (H % g.RH) return false;
+        g.tiles_per_img = H / g.RH;
+        g.n_tiles = B * g.tiles_per_img;
+    } else {
+        if (CT_PX % (H * W)) return false;
+        g.NI = CT_PX / (H * W);
+        g.RH = H;
+        g.tiles_per_img = 0;
+        g.n_tiles = (B + g.NI - 1) / g.NI;
+    }
+    g.WIN = g.NI * (g.RH + 2) * (W + 2);
+    g.M = B * H * W;
+    return g.WIN <= CT_MAXWIN;
+}
+
+// Window position of pixel p (0..63) of a tile: row-of-tile R = p / W; NI == 1: window row R + 1, else image R / H,
+// row R % H of that image.
+__device__ __forceinline__ int window_pos(const ConvTrainGeom& g, int p) {
+    const int R = p >> g.logW, x = p & (g.W - 1);
+    int wrow;
+    if (g.NI == 1) {
+        wrow = R + 1;
+    } else {
+        const int il = R / g.RH;
+        wrow = il * (g.RH + 2) + (R - il * g.RH) + 1;
+    }
+    return wrow * (g.W + 2) + x + 1;
+}
+
+// (image, row, column) of window element r (0..WIN-1) of tile `tile`; false when it lies outside every image (halo).
+__device__ __forceinline__ bool window_source(const ConvTrainGeom& g, int tile, int r, int& b, int& y, int& x) {
+    const int wrow = r / (g.W + 2);
+    x = r - wrow * (g.W + 2) - 1;
+    const int il = wrow / (g.RH + 2);
+    const int yy = wrow - il * (g.RH + 2);
+    if (g.NI == 1) {
+        b = tile / g.tiles_per_img;
+        y = (tile - b * g.tiles_per_img) * g.RH + yy - 1;
+    } else {
+        b = tile * g.NI + il;
+        y = yy - 1;
+    }
+    return b < g.B && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+}
+
+// (image, pixel offset inside the image) of pixel p of a tile; false past the last image.
+__device__ __forceinline__ bool tile_pixel(const ConvTrainGeom& g, int tile, int p, int& b, int& off) {
+    const int hw = g.H * g.W;
+    if (g.NI == 1) {
+        b = tile / g.tiles_per_img;
+        off = (tile - b * g.tiles_per_img) * CT_PX + p;
+    } else {
+        const int il = p / hw;
+        b = tile * g.NI + il;
+        off = p - il * hw;
+    }
+    return b < g.B;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward and data gradient.  out[b][n][p] = sum over reduction channels c and taps of A[n][(c, tap)] in[b][c][p + tap],
+//   forward (DGRAD = false): A[n][(c, tap)] = w[n][c][tap]         (w is [Nout][Cred][9])
+//   data gradient (true)   : A[n][(c, tap)] = w[c][n][8 - tap]     (w is [Cred][Nout][9]: the layer's own weight)
+// Workgroup: one pixel tile x 32 output channels x a range of 8-channel chunks (blockIdx.z: split reduction, slab z).
+// Wave w: pixel half w & 1 (one 32x32 accumulator), and half w >> 1 of a chunk's 36 two-deep steps (step = (channel
+// pair, tap); the lane half picks the channel of the pair); the two halves are added through LDS at the end.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__ in, const float* __restrict__ w,
+                                                       float* __restrict__ out, const ConvTrainGeom g, int Cred, int Nout,
+                                                       int chunks_per_split) {
+    __shared__ float win[CT_KC * CT_MAXWIN];
+    __shared__ float wts[CT_NO * CT_LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pt = wave & 1, kh = wave >> 1;
+    const int l32 = lane & 31, kk = lane >> 5;
+    const int tile = blockIdx.x, n0 = blockIdx.y * CT_NO;
+    const int nchunks = Cred / CT_KC;
+    const int c_begin = blockIdx.z * chunks_per_split, c_end = min(nchunks, c_begin + chunks_per_split);
+    const int hw = g.H * g.W;
+
+    // ---- what this thread stages per chunk: up to 8 window elements (offset relative to the chunk's first channel,
+    //      -1 = halo or past the tensor: zero) and 9 weights
+    constexpr int NE = CT_KC * CT_MAXWIN / 256;
+    int wsrc[NE];
+    const int n_win = CT_KC * g.WIN;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + 256 * i;
+        wsrc[i] = -1;
+        if (e < n_win) {
+            const int c = e / g.WIN, r = e - c * g.WIN;
+            int b, y, x;
+            if (window_source(g, tile, r, b, y, x)) wsrc[i] = ((b * Cred + c) * g.H + y) * g.W + x;
+        }
+    }
+    int asrc[9], adst[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int e = tid + 256 * i;  // 0 .. 2303
+        if (!DGRAD) {
+            const int n = e / 72, r = e - n * 72;  // r = (channel of the chunk, tap): 72 consecutive floats of w
+            asrc[i] = (n0 + n) * Cred * 9 + r;
+            adst[i] = n * CT_LDW + r;
+        } else {
+            const int c = e / 288, rem = e - c * 288;  // for one reduction channel: 32 output channels x 9 taps, consecutive
+            const int n = rem / 9, t = rem - n * 9;
+            asrc[i] = (c * Nout + n0 + n) * 9 + t;
+            adst[i] = n * CT_LDW + c * 9 + (8 - t);
+        }
+    }
+    float wreg[NE], areg[9];
+    auto load_chunk = [&](int c) {
+        const int in_off = c * CT_KC * hw;
+        const int w_off = DGRAD ? c * CT_KC * Nout * 9 : c * CT_KC * 9;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) wreg[i] = in[max(wsrc[i], 0) + in_off];  // unconditional (clamped), zeroed below
+#pragma unroll
+        for (int i = 0; i < 9; ++i) areg[i] = w[asrc[i] + w_off];
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            if (e < n_win) win[e] = wsrc[i] >= 0 ? wreg[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wts[adst[i]] = areg[i];
+    };
+
+    // ---- product loop
+    const int pos = window_pos(g, pt * 32 + l32);
+    int tapoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3 - 1) * (g.W + 2) + (t % 3 - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* arow = wts + l32 * CT_LDW + kk * 9;
+    const float* bcol = win + kk * g.WIN + pos;
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();  // the previous chunk has been multiplied
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);  // in flight while this chunk is multiplied
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int pair = kh * 2 + s / 9, t = s % 9;  // this wave's half of the 36 (channel pair, tap) steps
+            const float a = arow[pair * 18 + t];
+            const float b = bcol[pair * 2 * g.WIN + tapoff[t]];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    // ---- add the two halves of the steps (fixed order) and store
+    __syncthreads();
+    float* red = win;  // 2 x 16 x 64 floats
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(pt * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    int b, off;
+    const bool ok = tile_pixel(g, tile, pt * 32 + l32, b, off);
+    float* dst = out + (size_t)blockIdx.z * ((size_t)g.M * Nout);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r >> 2) * 8 + kk * 4 + (r & 3);
+        const float v = acc[r] + red[(pt * 16 + r) * 64 + lane];
+        if (ok) dst[((size_t)b * Nout + n) * hw + off] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  dw[co][ci][tap] = sum over pixels of dy[.][co][p] x[.][ci][p + tap].
+// Workgroup: 64 output channels x 32 input channels x a range of pixel tiles (blockIdx.z: slab z).  Wave w: output
+// channel half w & 1, and half w >> 1 of a tile's 32 pixel pairs; nine 32x32 accumulators (one per tap: rows = co,
+// columns = ci).  Per pixel pair one dy fragment serves nine matrix instructions.  The window rows are padded to an odd
+// length (lanes differ in ci).  At the end the two halves are added and the tile leaves through LDS as rows of
+// 32 x 9 consecutive floats of dw.
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad_train(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dw, const ConvTrainGeom g, int Cin, int Cout,
+                                                             int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDY = CT_PX + 1;
+    const int WINP = g.WIN | 1;
+    float* dyt = smem;                  // [64 co][65]
+    float* win = smem + 64 * LDY;       // [32 ci][WINP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cot = wave & 1, kh = wave >> 1;
+    const int l32 = lane & 31, kk = lane >> 5;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 64;
+    const int t_begin = blockIdx.z * tiles_per_split, t_end = min(g.n_tiles, t_begin + tiles_per_split);
+    const int hw = g.H * g.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int tapoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3 - 1) * (g.W + 2) + (t % 3 - 1);
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();  // the previous tile has been multiplied
+        {   // dy tile: 64 channels x 64 pixels.  A thread keeps one pixel and walks 16 channels (channel stride H W)
+            const int p = tid & 63, cq = tid >> 6;
+            int b, off;
+            const bool ok = tile_pixel(g, tile, p, b, off);
+            const float* src = dy + ((size_t)(ok ? b : 0) * Cout + co0 + cq) * hw + off;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = src[(size_t)(4 * i) * hw];  // unconditional: past the last image it re-reads image 0
+                dyt[(cq + 4 * i) * LDY + p] = ok ? v : 0.f;
+            }
+        }
+        if (tid < g.WIN) {  // window: a thread keeps one window position and walks the 32 channels
+            int b, y, xx;
+            const bool ok = window_source(g, tile, tid, b, y, xx);
+            const float* src = ok ? x + (((size_t)b * Cin + ci0) * g.H + y) * g.W + xx : x;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float v = src[(size_t)c * hw];
+                win[c * WINP + tid] = ok ? v : 0.f;
+            }
+        }
+        __syncthreads();
+        const float* arow = dyt + (cot * 32 + l32) * LDY + kk;
+        const float* bcol = win + l32 * WINP + kk;
+#pragma unroll 2
+        for (int s = 0; s < 16; ++s) {
+            const int p = 2 * (kh * 16 + s);
+            const int pos = __builtin_amdgcn_readfirstlane(window_pos(g, p));
+            const float a = arow[p];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcol[pos + tapoff[t]], acc[t], 0, 0, 0);
+        }
+    }
+
+    // ---- the two pixel halves added in a fixed order, one output-channel half at a time through LDS
+    float* dst = dw + (size_t)blockIdx.z * ((size_t)Cout * Cin * 9);
+    constexpr int LDO = 32 * 9 + 1;
+    float* ot = smem;  // [32 co][289]
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (cot == half && kh == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[((r >> 2) * 8 + kk * 4 + (r & 3)) * LDO + l32 * 9 + t] = acc[t][r];
+        }
+        __syncthreads();
+        if (cot == half && kh == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[((r >> 2) * 8 + kk * 4 + (r & 3)) * LDO + l32 * 9 + t] += acc[t][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * 288; e += 256) {
+            const int c = e / 288, r = e - c * 288;
+            dst[((size_t)(co0 + half * 32 + c) * Cin + ci0) * 9 + r] = ot[c * LDO + r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+
+namespace {
+
+struct ConvTrainPlan {
+    ConvTrainGeom g;
+    int ksplit, chunks_per_split;  // forward / data gradient over Cred
+};
+
+// split the reduction channels until the grid has a few hundred workgroups (two chunks per workgroup at least)
+void plan_split(const ConvTrainGeom& g, int Cred, int Nout, int& ksplit, int& cps) {
+    const int nchunks = Cred / CT_KC;
+    const long base = (long)g.n_tiles * (Nout / CT_NO);
+    ksplit = 1;
+    while (base * ksplit < 256 && nchunks / (ksplit * 2) >= 4 && ksplit < 16) ksplit *= 2;
+    cps = (nchunks + ksplit - 1) / ksplit;
+    ksplit = (nchunks + cps - 1) / cps;
+}
+
+void plan_wgrad(const ConvTrainGeom& g, int Cin, int Cout, int& slices, int& tps) {
+    const long tiles_out = (long)(Cin / 32) * (Cout / 64);
+    long s = (512 + tiles_out - 1) / tiles_out;
+    if (s > g.n_tiles) s = g.n_tiles;
+    if (s > 128) s = 128;
+    if (s < 1) s = 1;
+    tps = (int)((g.n_tiles + s - 1) / s);
+    slices = (g.n_tiles + tps - 1) / tps;
+}
+
+hipError_t sum_slabs(const float* part, float* out, size_t count, int slices, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((count / 4 + 31) / 32)), dim3(256), 0, stream, part, out, (int)(count / 4),
+                       slices);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv3x3_train_supported(int B, int Cin, int Cout, int H, int W) {
+    ConvTrainGeom g;
+    if (!make_geom(B, H, W, g)) return false;
+    // forward reduces over Cin (chunks of 8) into Cout (tiles of 32); the data gradient the other way round; the weight
+    // gradient works on 64 x 32 (Cout x Cin) tiles
+    if (Cin % 32 || Cout % 64) return false;
+    const long long big = (long long)B * (Cin > Cout ? Cin : Cout) * H * W;
+    return big < (1LL << 31) && (long long)Cin * Cout * 9 < (1LL << 31);
+}
+
+size_t conv3x3_train_workspace_floats(int B, int Cin, int Cout, int H, int W) {
+    ConvTrainGeom g;
+    if (!make_geom(B, H, W, g)) return 0;
+    int ks, cps, sl, tps;
+    size_t need = 4;
+    plan_split(g, Cin, Cout, ks, cps);
+    if (ks > 1) need = std::max(need, (size_t)ks * g.M * Cout);
+    plan_split(g, Cout, Cin, ks, cps);
+    if (ks > 1) need = std::max(need, (size_t)ks * g.M * Cin);
+    plan_wgrad(g, Cin, Cout, sl, tps);
+    if (sl > 1) need = std::max(need, (size_t)sl * Cin * Cout * 9);
+    return need;
+}
+
+// dgrad = false: in = x [B][Cin][H][W], out = y [B][Cout][H][W]; true: in = dy [B][Cout][H][W], out = dx [B][Cin][H][W]
+hipError_t launch_conv3x3_train(bool dgrad, const float* in, const float* w, float* out, int B, int Cin, int Cout, int H,
+                                int W, float* workspace, hipStream_t stream) {
+    ConvTrainGeom g;
+    if (!make_geom(B, H, W, g)) return hipErrorInvalidValue;
+    const int Cred = dgrad ? Cout : Cin, Nout = dgrad ? Cin : Cout;
+    int ks, cps;
+    plan_split(g, Cred, Nout, ks, cps);
+    float* dst = ks > 1 ? workspace : out;
+    const dim3 grid(g.n_tiles, Nout / CT_NO, ks);
+    if (dgrad) hipLaunchKernelGGL(k_conv3x3_train<true>, grid, dim3(256), 0, stream, in, w, dst, g, Cred, Nout, cps);
+    else hipLaunchKernelGGL(k_conv3x3_train<false>, grid, dim3(256), 0, stream, in, w, dst, g, Cred, Nout, cps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return sum_slabs(workspace, out, (size_t)g.M * Nout, ks, stream);
+}
+
+hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                      float* workspace, hipStream_t stream) {
+    ConvTrainGeom g;
+    if (!make_geom(B, H, W, g)) return hipErrorInvalidValue;
+    int sl, tps;
+    plan_wgrad(g, Cin, Cout, sl, tps);
+    const size_t loop_floats = 64 * (CT_PX + 1) + 32 * (size_t)(g.WIN | 1);
+    const size_t out_floats = 32 * (32 * 9 + 1);
+    const size_t lds = std::max(loop_floats, out_floats) * sizeof(float);
+    float* dst = sl > 1 ? workspace : dw;
+    hipLaunchKernelGGL(k_conv3x3_wgrad_train, dim3(Cin / 32, Cout / 64, sl), dim3(256), lds, stream, x, dy, dst, g, Cin, Cout,
+                       tps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || sl == 1) return e;
+    return sum_slabs(workspace, dw, (size_t)Cin * Cout * 9, sl, stream);
+}
+
+}  // namespace danra

@@ -20,6 +20,8 @@ NOISE_PHILOX = 1
 # The kernels of the differentiable path (attention core, train-mode BatchNorm, InstanceNorm: forward and backward).
 # False sends that path through torch's own operators everywhere - for comparisons; the inference path is not affected.
 native_training_kernels = True
+# the 3x3 stride-1 convolutions of the training step in the native library as well (False: torch's own, for comparisons)
+native_training_convolutions = True
 
 
 class DanraConfig(ctypes.Structure):
@@ -72,6 +74,11 @@ _SIGNATURES = {
     "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "danra_conv3x3_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "danra_conv3x3_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "danra_conv3x3_train_fwd": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
+    "danra_conv3x3_train_dgrad": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
+    "danra_conv3x3_train_wgrad": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_set_graph_mode": (ctypes.c_int, [_P, ctypes.c_int]),
     "danra_set_first_image": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "danra_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
@@ -398,6 +405,65 @@ def instance_norm(module, x):
             and (x.shape[2] * x.shape[3]) % 4 == 0 and x.numel() < (1 << 31)):
         return _InstanceNorm.apply(x, float(module.eps))
     return module(x)
+
+
+class _Conv3x3Train(torch.autograd.Function):
+    """torch.nn.functional.conv2d(x, weight, None, stride=1, padding=1) for a 3x3 kernel on a contiguous NCHW fp32 CUDA
+    tensor, forward, data gradient and weight gradient in libdanra_hip.so (danra_conv3x3_train_fwd / _dgrad / _wgrad):
+    the tensors and the [Cout][Cin][3][3] weight are used where they lie, no layout conversion around a call."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight):
+        lib = load_library()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(lib.danra_conv3x3_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_conv3x3_train_fwd(_ptr(x), _ptr(weight), _ptr(y), B, Cin, Cout, H, W, _ptr(ws), _stream()),
+                   "danra_conv3x3_train_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = _f32(dy, "dy")
+        ws = torch.empty(max(lib.danra_conv3x3_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=x.device, dtype=torch.float32)
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(lib, lib.danra_conv3x3_train_dgrad(_ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W, _ptr(ws),
+                                                          _stream()), "danra_conv3x3_train_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                _check(lib, lib.danra_conv3x3_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
+                                                          _stream()), "danra_conv3x3_train_wgrad")
+        return dx, dw
+
+
+def conv2d(conv, x):
+    """``conv(x)`` for an nn.Conv2d.  A 3x3, stride-1, padding-1, ungrouped convolution on a 4-D CUDA tensor (float32; half
+    precision under autocast) with gradients enabled - the training step - runs forward and backward in the native library
+    where it has the shape (danra_conv3x3_train_supported); the bias, if any, is added by torch.  Everything else is the
+    module itself."""
+    if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
+            and type(conv) is torch.nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and _native_dtype(x)
+            and conv.weight.dtype == torch.float32 and (x.requires_grad or conv.weight.requires_grad)):
+        B, Cin, H, W = x.shape
+        if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
+            y = _Conv3x3Train.apply(x, conv.weight)
+            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    return conv(x)
 
 
 class UNetEngine:

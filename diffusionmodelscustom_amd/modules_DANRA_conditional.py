@@ -224,8 +224,8 @@ class DecoderBlock(nn.Module):
     def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
         up = self.transpose(fmap)
         if up.is_cuda:  # the two norms run forward and backward in the native library where it has them
-            from .hip_engine import instance_norm
-            out = instance_norm(self.instance_norm2, self.conv(instance_norm(self.instance_norm1, up)))
+            from .hip_engine import conv2d, instance_norm
+            out = instance_norm(self.instance_norm2, conv2d(self.conv, instance_norm(self.instance_norm1, up)))
         else:
             out = self.instance_norm2(self.conv(self.instance_norm1(up)))
         if out.requires_grad:

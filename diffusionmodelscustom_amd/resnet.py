@@ -8,7 +8,16 @@ initialisation, and the block arithmetic for the autograd path.  No torchvision 
 """
 import torch.nn as nn
 
-__all__ = ["BasicBlock", "ResNet", "norm_relu"]
+__all__ = ["BasicBlock", "ResNet", "norm_relu", "conv2d"]
+
+
+def conv2d(conv, x):
+    """``conv(x)``; on a CUDA tensor with gradients enabled a 3x3 stride-1 convolution runs forward and backward in
+    ``libdanra_hip.so`` where it has the shape (hip_engine.conv2d)."""
+    if x.is_cuda:
+        from . import hip_engine
+        return hip_engine.conv2d(conv, x)
+    return conv(x)
 
 
 def norm_relu(bn, relu, x):
@@ -44,8 +53,8 @@ class BasicBlock(nn.Module):
             shortcut = norm_relu(self.downsample[1], None, self.downsample[0](x))
         else:
             shortcut = self.downsample(x)
-        y = norm_relu(self.bn1, self.relu, self.conv1(x))
-        y = norm_relu(self.bn2, None, self.conv2(y))
+        y = norm_relu(self.bn1, self.relu, conv2d(self.conv1, x))
+        y = norm_relu(self.bn2, None, conv2d(self.conv2, y))
         return self.relu(y + shortcut)
 
 

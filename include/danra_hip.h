@@ -207,6 +207,23 @@ size_t danra_linear_wgrad_workspace(int M, int N, int K);
 int danra_linear_wgrad(const float* dy_dev, const float* x_dev, float* dw_dev, float* db_dev, int M, int N, int K,
                        void* workspace_dev, void* stream);
 
+/* The 3x3, stride-1, padding-1 convolutions of the training step (torchvision BasicBlock conv1 / conv2 of stride 1,
+ * modules_DANRA_conditional.py:154,276-303, and the decoder blocks' nn.Conv2d(k=3, padding=1), modules_DANRA_conditional.py:417)
+ * as autograd runs them in training_DANRA_conditional.py:962-984: forward y = conv(x, w), data gradient
+ * dx = conv_transpose(dy, w), weight gradient dw = sum over batch and pixels of dy (x) x-windows.  Contiguous NCHW fp32
+ * tensors and the [Cout][Cin][3][3] weight as nn.Conv2d holds it; no bias (the caller adds it).  Supported
+ * (danra_conv3x3_train_supported): Cin a multiple of 32, Cout a multiple of 64, W a power of two in 2..64, and either
+ * H*W >= 64 with H a multiple of 64/W, or H*W a divisor of 64.  workspace: danra_conv3x3_train_workspace(...) bytes of
+ * device memory, the caller's (nothing is allocated); sums over workgroups are formed in a fixed order (bit-reproducible). */
+int danra_conv3x3_train_supported(int B, int Cin, int Cout, int H, int W);
+size_t danra_conv3x3_train_workspace(int B, int Cin, int Cout, int H, int W);
+int danra_conv3x3_train_fwd(const float* x_dev, const float* w_dev, float* y_dev, int B, int Cin, int Cout, int H, int W,
+                            void* workspace_dev, void* stream);
+int danra_conv3x3_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int Cout, int H, int W,
+                              void* workspace_dev, void* stream);
+int danra_conv3x3_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
+                              void* workspace_dev, void* stream);
+
 /* Batch sharding of the in-kernel noise (no counterpart in the reference, which samples on one device): the calls
  * to danra_sample / danra_sample_guided that follow treat their image 0 as image `first_image` of a larger batch:
  * with DANRA_NOISE_PHILOX the draw for element e of local image b at a timestep is that of global element

@@ -479,16 +479,19 @@ def test_token_linear_equals_torch_linear():
 
 def native_call_counters(monkeypatch):
     names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
-             "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad")
+             "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
+             "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
 # the conditional network: 4 attention blocks at 64 channels (core forward and backward, and the weight gradients of their
 # two projections); bn1 + 8 blocks x 2 + 3 shortcut norms; 4 decoder blocks x 2 InstanceNorms + the final block's first
-# (its second is an Identity)
+# (its second is an Identity); the 3x3 stride-1 convolutions: 4 + 3 + 3 + 3 in the BasicBlocks (the first convolution of
+# layers 2-4 has stride 2) and the four decoder blocks' (the final block's has one output channel), each in three directions
 EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 20,
                          "danra_batchnorm_train_bwd": 20, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
-                         "danra_linear_wgrad": 8}
+                         "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
+                         "danra_conv3x3_train_wgrad": 17}
 
 
 def test_train_mode_network_uses_the_native_kernels(monkeypatch):

@@ -1,0 +1,110 @@
+"""The training step's 3x3 stride-1 convolutions in the native library (danra_conv3x3_train_fwd / _dgrad / _wgrad)
+against torch's own arithmetic.
+
+The checker is what the reference's training loop runs for these layers - torch.nn.functional.conv2d and its autograd
+backward (torchvision BasicBlock conv1 / conv2 and the decoder blocks' nn.Conv2d, modules_DANRA_conditional.py:154,417;
+training_DANRA_conditional.py:962-984) - evaluated in float64.  Tolerance: 1e-5 * max|.| per tensor, the per-op bar of
+the inference kernels.
+"""
+import pytest
+import torch
+
+from diffusionmodelscustom_amd import hip_engine
+from diffusionmodelscustom_amd.hip_engine import _check, _ptr, _stream
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_native(x, w, dy):
+    lib = hip_engine.load_library()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert lib.danra_conv3x3_train_supported(B, Cin, Cout, H, W)
+    ws = torch.empty(max(lib.danra_conv3x3_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=DEV)
+    y = torch.empty((B, Cout, H, W), device=DEV)
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    _check(lib, lib.danra_conv3x3_train_fwd(_ptr(x), _ptr(w), _ptr(y), B, Cin, Cout, H, W, _ptr(ws), _stream()), "fwd")
+    _check(lib, lib.danra_conv3x3_train_dgrad(_ptr(dy), _ptr(w), _ptr(dx), B, Cin, Cout, H, W, _ptr(ws), _stream()), "dgrad")
+    _check(lib, lib.danra_conv3x3_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws), _stream()), "wgrad")
+    torch.cuda.synchronize()
+    return y, dx, dw
+
+
+def close(got, want, what, tol=1e-5):
+    err = (got.double() - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= tol * ref, f"{what}: max error {err:.3e} against max |.| {ref:.3e} (tolerance {tol:g} relative)"
+
+
+# every 3x3 stride-1 convolution shape of the 64x64 and 128x128 networks (batch sizes chosen so that tiles are cut:
+# 5 images of 2x2 leave an eleven-image hole in the only pixel tile, 3 images of 4x4 one of one image), a batch large
+# enough for the pixel slices of the weight gradient, and a rectangular map
+SHAPES = [
+    (3, 64, 64, 16, 16), (2, 128, 128, 8, 8), (3, 256, 256, 4, 4), (5, 512, 512, 2, 2),
+    (3, 512, 256, 4, 4), (2, 256, 128, 8, 8), (2, 128, 64, 16, 16), (2, 64, 64, 32, 32),
+    (1, 64, 64, 64, 64), (32, 64, 64, 16, 16), (32, 512, 512, 2, 2), (2, 64, 128, 8, 16),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", SHAPES)
+def test_convolution_kernels_match_float64(B, Cin, Cout, H, W):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(DEV)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    y, dx, dw = run_native(x, w, dy)
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)  # the float64 arbiter, on the CPU
+    want = torch.nn.functional.conv2d(xd, wd, None, 1, 1)
+    want.backward(dy.double().cpu())
+    close(y.cpu(), want.detach(), "forward")
+    close(dx.cpu(), xd.grad, "data gradient")
+    close(dw.cpu(), wd.grad, "weight gradient")
+    again = run_native(x, w, dy)
+    for a, b, what in zip((y, dx, dw), again, ("forward", "data gradient", "weight gradient")):
+        assert torch.equal(a, b), f"{what}: two calls differ"
+
+
+def test_unsupported_shapes_are_refused():
+    lib = hip_engine.load_library()
+    for B, Cin, Cout, H, W in [(2, 64, 1, 64, 64), (2, 4, 64, 64, 64), (2, 64, 64, 128, 128), (2, 64, 64, 6, 6),
+                               (2, 64, 64, 3, 16), (0, 64, 64, 8, 8)]:
+        assert not lib.danra_conv3x3_train_supported(B, Cin, Cout, H, W), (B, Cin, Cout, H, W)
+        assert lib.danra_conv3x3_train_workspace(B, Cin, Cout, H, W) == 0
+    x = torch.zeros(2, 64, 6, 6, device=DEV)
+    w = torch.zeros(64, 64, 3, 3, device=DEV)
+    rc = lib.danra_conv3x3_train_fwd(_ptr(x), _ptr(w), _ptr(x), 2, 64, 64, 6, 6, _ptr(x), _stream())
+    assert rc != 0 and b"danra_conv3x3_train_supported" in lib.danra_last_error()
+
+
+def test_conv2d_function_equals_the_torch_module(monkeypatch):
+    """hip_engine.conv2d on an nn.Conv2d with a bias (a decoder block's convolution): output and all three gradients
+    against the module itself, and the module is what runs when the shape or the mode is not the library's."""
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(128, 64, 3, 1, 1).to(DEV)
+    x = torch.randn(4, 128, 16, 16, device=DEV, requires_grad=True)
+    dy = torch.randn(4, 64, 16, 16, device=DEV)
+    calls = []
+    lib = hip_engine.load_library()
+    for name in ("danra_conv3x3_train_fwd", "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad"):
+        real = getattr(lib, name)
+        monkeypatch.setattr(lib, name, lambda *a, _r=real, _n=name: (calls.append(_n), _r(*a))[1])
+    y = hip_engine.conv2d(conv, x)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    assert sorted(calls) == ["danra_conv3x3_train_dgrad", "danra_conv3x3_train_fwd", "danra_conv3x3_train_wgrad"]
+    conv64 = torch.nn.Conv2d(128, 64, 3, 1, 1).double()
+    conv64.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = conv64(x64)
+    y64.backward(dy.double().cpu())
+    for a, b, what in zip(got, (y64.detach(), x64.grad, conv64.weight.grad, conv64.bias.grad),
+                          ("output", "input gradient", "weight gradient", "bias gradient")):
+        close(a.cpu(), b, what)
+    del calls[:]
+    with torch.no_grad():
+        hip_engine.conv2d(conv, x)                                    # no gradient: the module
+    hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 1).to(DEV), x)   # stride 2: the module
+    hip_engine.conv2d(torch.nn.Conv2d(128, 1, 3, 1, 1).to(DEV), x)    # one output channel: the module
+    assert calls == []

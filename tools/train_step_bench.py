@@ -113,25 +113,32 @@ def main():
                                     "peak_GiB": round(gib, 2), "last_loss": loss}
     # the same step replayed from one hipGraph (diffusionmodelscustom_amd.training.GraphedTrainStep)
     from diffusionmodelscustom_amd.training import GraphedTrainStep
-    model = build(a.size, dev)
-    # fused: one multi-tensor kernel per step; the plain capturable form launches ~300 scalar copy kernels per step
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True, fused=True)
     x, y, planes = data
-    step = GraphedTrainStep(model, opt, du, torch.nn.MSELoss(), dict(images=x, seasons=y, cond_images=planes[0],
-                                                                     lsm=planes[1], topo=planes[2]))
-    torch.cuda.reset_peak_memory_stats()
-    for _ in range(a.warmup):
-        step(x, y, *planes)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step(x, y, *planes)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / a.steps * 1e3
-    out["native_kernels_graphed"] = {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
-                                            "peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                                            "last_loss": float(loss)}
-    del step, opt, model
+
+    def graphed():
+        model = build(a.size, dev)
+        # fused: one multi-tensor kernel per step; the plain capturable form launches ~300 scalar copy kernels per step
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True, fused=True)
+        step = GraphedTrainStep(model, opt, du, torch.nn.MSELoss(), dict(images=x, seasons=y, cond_images=planes[0],
+                                                                         lsm=planes[1], topo=planes[2]))
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(a.warmup):
+            step(x, y, *planes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step(x, y, *planes)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        return {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch / ms * 1e3, 1),
+                "peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "last_loss": float(loss)}
+
+    out["native_kernels_graphed"] = graphed()
+    hip_engine.native_training_convolutions = False  # the 3x3 convolutions back on torch's own kernels, everything else native
+    try:
+        out["native_kernels_graphed_torch_convolutions"] = graphed()
+    finally:
+        hip_engine.native_training_convolutions = True
     hip_engine.native_training_kernels = False   # the same step with torch's own attention / BatchNorm / InstanceNorm
     try:
         model = build(a.size, dev)
