@@ -1229,6 +1229,24 @@ int danra_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
     return DANRA_OK;
 }
 
+int danra_linear_supported(int M, int N, int K) {
+    return (M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 32 == 0 && (long long)M * N < (1LL << 31) &&
+            (long long)M * K < (1LL << 31)) ? 1 : 0;
+}
+
+int danra_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, void* stream) {
+    if (!x || !w || !y) return fail(DANRA_EINVAL, "null argument");
+    if (!danra_linear_supported(M, N, K))
+        return fail(DANRA_EINVAL, "M=%d N=%d K=%d: N must be a multiple of 64, K of 32, fewer than 2^31 elements", M, N, K);
+    IGemmArgs a = blank_args();
+    a.A = x; a.lda = K; a.a_mode = A_GEMM;
+    a.W = w; a.bias = bias; a.out = y;
+    a.M = M; a.N = N; a.K = K;
+    a.st_mode = ST_ROW; a.ldc = N;
+    HIP_TRY(launch_igemm(a, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_conv3x3_train_supported(int B, int Cin, int Cout, int H, int W) {
     return conv3x3_train_supported(B, Cin, Cout, H, W) ? 1 : 0;
 }

@@ -28,9 +28,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int CT_PX = 64;    // pixels per tile
-constexpr int CT_KC = 8;     // reduction channels per chunk (forward / data gradient)
+constexpr int CT_KC = 16;    // reduction channels per chunk (forward / data gradient)
 constexpr int CT_NO = 32;    // output channels per workgroup (forward / data gradient)
-constexpr int CT_LDW = 73;   // LDS row of the staged weights: 8 channels x 9 taps + 1 (odd: conflict-free column reads)
+constexpr int CT_LDW = CT_KC * 9 + 1;  // LDS row of the staged weights: 16 channels x 9 taps + 1 (odd: conflict-free column reads)
 constexpr int CT_MAXWIN = 256;  // largest window per channel: 16 images of 2x2 -> 16 x 4 x 4
 
 struct ConvTrainGeom {
@@ -115,8 +115,8 @@ __device__ __forceinline__ bool tile_pixel(const ConvTrainGeom& g, int tile, int
 // Forward and data gradient.  out[b][n][p] = sum over reduction channels c and taps of A[n][(c, tap)] in[b][c][p + tap],
 //   forward (DGRAD = false): A[n][(c, tap)] = w[n][c][tap]         (w is [Nout][Cred][9])
 //   data gradient (true)   : A[n][(c, tap)] = w[c][n][8 - tap]     (w is [Cred][Nout][9]: the layer's own weight)
-// Workgroup: one pixel tile x 32 output channels x a range of 8-channel chunks (blockIdx.z: split reduction, slab z).
-// Wave w: pixel half w & 1 (one 32x32 accumulator), and half w >> 1 of a chunk's 36 two-deep steps (step = (channel
+// Workgroup: one pixel tile x 32 output channels x a range of 16-channel chunks (blockIdx.z: split reduction, slab z).
+// Wave w: pixel half w & 1 (one 32x32 accumulator), and half w >> 1 of a chunk's 72 two-deep steps (step = (channel
 // pair, tap); the lane half picks the channel of the pair); the two halves are added through LDS at the end.
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__ in, const float* __restrict__ w,
@@ -132,27 +132,25 @@ __global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__
     const int c_begin = blockIdx.z * chunks_per_split, c_end = min(nchunks, c_begin + chunks_per_split);
     const int hw = g.H * g.W;
 
-    // ---- what this thread stages per chunk: up to 8 window elements (offset relative to the chunk's first channel,
-    //      -1 = halo or past the tensor: zero) and 9 weights
-    constexpr int NE = CT_KC * CT_MAXWIN / 256;
-    int wsrc[NE];
-    const int n_win = CT_KC * g.WIN;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + 256 * i;
-        wsrc[i] = -1;
-        if (e < n_win) {
-            const int c = e / g.WIN, r = e - c * g.WIN;
-            int b, y, x;
-            if (window_source(g, tile, r, b, y, x)) wsrc[i] = ((b * Cred + c) * g.H + y) * g.W + x;
-        }
+    // ---- what this thread stages per chunk.  Window: the thread owns ONE window position (tid % WP, WP = 128 or 256
+    //      >= WIN) and walks the chunk's channels with stride 256 / WP (offset -1 = halo or past the tensor: zero); one
+    //      position decode per thread.  Weights: 18 values.
+    const int wp_log = g.WIN <= 128 ? 7 : 8;
+    const int wr = tid & ((1 << wp_log) - 1), wc0 = tid >> wp_log, wcs = 256 >> wp_log;  // position, first channel, stride
+    constexpr int NE = CT_KC;  // loads per thread when one thread group walks all channels (WP = 256)
+    int wsrc = -1;
+    if (wr < g.WIN) {
+        int b, y, x;
+        if (window_source(g, tile, wr, b, y, x)) wsrc = ((b * Cred + wc0) * g.H + y) * g.W + x;
     }
-    int asrc[9], adst[9];
+    const int n_mine = CT_KC / wcs;  // channels this thread loads per chunk: 16 or 8
+    constexpr int NA = CT_NO * CT_KC * 9 / 256;  // 18
+    int asrc[NA], adst[NA];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int e = tid + 256 * i;  // 0 .. 2303
+    for (int i = 0; i < NA; ++i) {
+        const int e = tid + 256 * i;
         if (!DGRAD) {
-            const int n = e / 72, r = e - n * 72;  // r = (channel of the chunk, tap): 72 consecutive floats of w
+            const int n = e / (CT_KC * 9), r = e - n * (CT_KC * 9);  // r = (channel of the chunk, tap): consecutive floats of w
             asrc[i] = (n0 + n) * Cred * 9 + r;
             adst[i] = n * CT_LDW + r;
         } else {
@@ -162,23 +160,24 @@ __global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__
             adst[i] = n * CT_LDW + c * 9 + (8 - t);
         }
     }
-    float wreg[NE], areg[9];
+    float wreg[NE], areg[NA];
     auto load_chunk = [&](int c) {
-        const int in_off = c * CT_KC * hw;
+        const float* src = in + c * CT_KC * hw + max(wsrc, 0);  // unconditional (clamped) loads, zeroed when stored
         const int w_off = DGRAD ? c * CT_KC * Nout * 9 : c * CT_KC * 9;
 #pragma unroll
-        for (int i = 0; i < NE; ++i) wreg[i] = in[max(wsrc[i], 0) + in_off];  // unconditional (clamped), zeroed below
+        for (int i = 0; i < NE; ++i)
+            if (i < n_mine) wreg[i] = src[i * wcs * hw];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) areg[i] = w[asrc[i] + w_off];
+        for (int i = 0; i < NA; ++i) areg[i] = w[asrc[i] + w_off];
     };
     auto store_chunk = [&]() {
+        if (wr < g.WIN) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i;
-            if (e < n_win) win[e] = wsrc[i] >= 0 ? wreg[i] : 0.f;
+            for (int i = 0; i < NE; ++i)
+                if (i < n_mine) win[(wc0 + i * wcs) * g.WIN + wr] = wsrc >= 0 ? wreg[i] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) wts[adst[i]] = areg[i];
+        for (int i = 0; i < NA; ++i) wts[adst[i]] = areg[i];
     };
 
     // ---- product loop
@@ -199,8 +198,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);  // in flight while this chunk is multiplied
 #pragma unroll
-        for (int s = 0; s < 18; ++s) {
-            const int pair = kh * 2 + s / 9, t = s % 9;  // this wave's half of the 36 (channel pair, tap) steps
+        for (int s = 0; s < CT_KC / 4 * 9; ++s) {
+            const int pair = kh * (CT_KC / 4) + s / 9, t = s % 9;  // this wave's half of the (channel pair, tap) steps
             const float a = arow[pair * 18 + t];
             const float b = bcol[pair * 2 * g.WIN + tapoff[t]];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -232,8 +231,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_train(const float* __restrict__
 // Workgroup: 64 output channels x 32 input channels x a range of pixel tiles (blockIdx.z: slab z).  Wave w: output
 // channel half w & 1, and half w >> 1 of a tile's 32 pixel pairs; nine 32x32 accumulators (one per tap: rows = co,
 // columns = ci).  Per pixel pair one dy fragment serves nine matrix instructions.  The window rows are padded to an odd
-// length (lanes differ in ci).  At the end the two halves are added and the tile leaves through LDS as rows of
-// 32 x 9 consecutive floats of dw.
+// length (lanes differ in ci).
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad_train(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ dw, const ConvTrainGeom g, int Cin, int Cout,
                                                              int tiles_per_split) {
@@ -295,29 +293,28 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_train(const float* __rest
         }
     }
 
-    // ---- the two pixel halves added in a fixed order, one output-channel half at a time through LDS
+    // ---- the two pixel halves are added in a fixed order through LDS, register by register in lane order (conflict-free),
+    //      one output-channel half at a time; the sums are stored from the registers: lane (ci, kk) writes the nine taps
+    //      of its (co, ci) pairs, 36 consecutive bytes each (the stores of a pair merge in L2)
     float* dst = dw + (size_t)blockIdx.z * ((size_t)Cout * Cin * 9);
-    constexpr int LDO = 32 * 9 + 1;
-    float* ot = smem;  // [32 co][289]
+    float* red = smem;  // [9 taps][16 registers][64 lanes]
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
         if (cot == half && kh == 1) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ot[((r >> 2) * 8 + kk * 4 + (r & 3)) * LDO + l32 * 9 + t] = acc[t][r];
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
         }
         __syncthreads();
         if (cot == half && kh == 0) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + half * 32 + (r >> 2) * 8 + kk * 4 + (r & 3);
+                float* o = dst + ((size_t)co * Cin + ci0 + l32) * 9;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ot[((r >> 2) * 8 + kk * 4 + (r & 3)) * LDO + l32 * 9 + t] += acc[t][r];
-        }
-        __syncthreads();
-        for (int e = tid; e < 32 * 288; e += 256) {
-            const int c = e / 288, r = e - c * 288;
-            dst[((size_t)(co0 + half * 32 + c) * Cin + ci0) * 9 + r] = ot[c * LDO + r];
+                for (int t = 0; t < 9; ++t) o[t] = acc[t][r] + red[(t * 16 + r) * 64 + lane];
+            }
         }
     }
 }
@@ -344,7 +341,7 @@ void plan_split(const ConvTrainGeom& g, int Cred, int Nout, int& ksplit, int& cp
 
 void plan_wgrad(const ConvTrainGeom& g, int Cin, int Cout, int& slices, int& tps) {
     const long tiles_out = (long)(Cin / 32) * (Cout / 64);
-    long s = (512 + tiles_out - 1) / tiles_out;
+    long s = tiles_out >= 128 ? 1 : (512 + tiles_out - 1) / tiles_out;  // (slabs of a 512 x 512 x 9 gradient are 9.4 MB each)
     if (s > g.n_tiles) s = g.n_tiles;
     if (s > 128) s = 128;
     if (s < 1) s = 1;
@@ -408,7 +405,7 @@ hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw
     int sl, tps;
     plan_wgrad(g, Cin, Cout, sl, tps);
     const size_t loop_floats = 64 * (CT_PX + 1) + 32 * (size_t)(g.WIN | 1);
-    const size_t out_floats = 32 * (32 * 9 + 1);
+    const size_t out_floats = 9 * 16 * 64;
     const size_t lds = std::max(loop_floats, out_floats) * sizeof(float);
     float* dst = sl > 1 ? workspace : dw;
     hipLaunchKernelGGL(k_conv3x3_wgrad_train, dim3(Cin / 32, Cout / 64, sl), dim3(256), lds, stream, x, dy, dst, g, Cin, Cout,

@@ -74,6 +74,8 @@ _SIGNATURES = {
     "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "danra_linear_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "danra_linear": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_conv3x3_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "danra_conv3x3_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "danra_conv3x3_train_fwd": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
@@ -253,31 +255,47 @@ def attention_core_supported(tokens, n_heads):
 
 
 class _TokenLinear(torch.autograd.Function):
-    """torch.nn.functional.linear(x, weight, bias) on [..., K] fp32 CUDA tokens whose weight and bias gradients are formed
-    in libdanra_hip.so (danra_linear_wgrad): grad_weight = dy^T x is a product with a few thousand output values and a
-    reduction over every token of the batch (8192 ... 131072 rows), which the BLAS library behind torch.mm runs at 60-130 us
-    per call on MI355X; the forward product and the input gradient stay torch's."""
+    """torch.nn.functional.linear(x, weight, bias) on [..., K] fp32 CUDA tokens, forward and backward in libdanra_hip.so:
+    the product and the input gradient through danra_linear (the implicit-GEMM kernel with fp32 matrix instructions; for
+    these tall, narrow products - 8192 ... 131072 rows, 64 ... 192 columns - the BLAS library behind torch.mm picks tiles of
+    256 x 256 and takes 60-130 us per call on MI355X), weight and bias gradient through danra_linear_wgrad (a reduction
+    over every token of the batch into a few thousand values)."""
 
     @staticmethod
     @_custom_fwd
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        return torch.nn.functional.linear(x, weight, bias)
+        lib = load_library()
+        N, K = weight.shape
+        x2 = x.reshape(-1, K).contiguous()
+        weight = weight.contiguous()
+        M = x2.shape[0]
+        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_linear(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), M, N, K, _stream()), "danra_linear")
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        return y
 
     @staticmethod
     @_custom_bwd
     def backward(ctx, dy):
         lib = load_library()
-        x, weight = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         N, K = weight.shape
         dy2 = _f32(dy, "dy").reshape(-1, N)
-        x2 = x.reshape(-1, K).contiguous()
         M = x2.shape[0]
-        dx = dy2.matmul(weight).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(weight)
-        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        dx = None
+        with torch.cuda.device(x2.device):
+            if ctx.needs_input_grad[0]:
+                if lib.danra_linear_supported(M, K, N):  # dx = dy W = dy (W^T)^T
+                    dx = torch.empty(ctx.x_shape, device=x2.device, dtype=torch.float32)
+                    wt = weight.t().contiguous()
+                    _check(lib, lib.danra_linear(_ptr(dy2), _ptr(wt), None, _ptr(dx), M, K, N, _stream()), "danra_linear")
+                else:
+                    dx = dy2.matmul(weight).view(ctx.x_shape)
+            dw = torch.empty_like(weight)
+            db = torch.empty(N, device=x2.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x2.device, dtype=torch.float32)
             _check(lib, lib.danra_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db) if db is not None else None, M, N, K,
                                                _ptr(workspace), _stream()), "danra_linear_wgrad")
         return dx, dw, db
@@ -291,7 +309,8 @@ def token_linear(x, weight, bias):
             and bias is not None and torch.is_grad_enabled()):
         N, K = weight.shape
         M = x.numel() // K
-        if load_library().danra_linear_wgrad_supported(M, N, K):
+        lib = load_library()
+        if lib.danra_linear_wgrad_supported(M, N, K) and lib.danra_linear_supported(M, N, K):
             return _TokenLinear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
 

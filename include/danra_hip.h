@@ -207,6 +207,14 @@ size_t danra_linear_wgrad_workspace(int M, int N, int K);
 int danra_linear_wgrad(const float* dy_dev, const float* x_dev, float* dw_dev, float* db_dev, int M, int N, int K,
                        void* workspace_dev, void* stream);
 
+/* y = x W^T + b on M rows: torch.nn.functional.linear as nn.MultiheadAttention applies its in_proj / out_proj
+ * (modules_DANRA_conditional.py:84,105), and - called with W^T - the input gradient dx = dy W of such a layer in the
+ * training step (training_DANRA_conditional.py:962-984).  x: [M][K], w: [N][K], bias: [N] or NULL, y: [M][N], row-major
+ * fp32; fp32 matrix instructions.  Supported: N a multiple of 64, K a multiple of 32 (danra_linear_supported). */
+int danra_linear_supported(int M, int N, int K);
+int danra_linear(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int M, int N, int K,
+                 void* stream);
+
 /* The 3x3, stride-1, padding-1 convolutions of the training step (torchvision BasicBlock conv1 / conv2 of stride 1,
  * modules_DANRA_conditional.py:154,276-303, and the decoder blocks' nn.Conv2d(k=3, padding=1), modules_DANRA_conditional.py:417)
  * as autograd runs them in training_DANRA_conditional.py:962-984: forward y = conv(x, w), data gradient

@@ -461,20 +461,25 @@ def test_linear_weight_gradient_kernel_against_float64(M, N):
 
 
 def test_token_linear_equals_torch_linear():
-    """hip_engine.token_linear against torch.nn.functional.linear: same forward bits, gradients within 1e-5 (the weight
-    and bias gradients come from the native kernel, the input gradient from torch)."""
+    """hip_engine.token_linear against torch.nn.functional.linear evaluated in float64: output and the three gradients
+    within 1e-5 (product and input gradient from danra_linear, weight and bias gradients from danra_linear_wgrad), and
+    bit-identical between two calls."""
     torch.manual_seed(5)
     x = torch.randn(4, 1024, 64, device=DEV, requires_grad=True)
     w = torch.randn(192, 64, device=DEV, requires_grad=True)
     b = torch.randn(192, device=DEV, requires_grad=True)
     up = torch.randn(4, 1024, 192, device=DEV)
-    y0 = torch.nn.functional.linear(x, w, b)
-    g0 = torch.autograd.grad(y0, (x, w, b), up)
+    x64, w64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (x, w, b))
+    y0 = torch.nn.functional.linear(x64, w64, b64)
+    g0 = torch.autograd.grad(y0, (x64, w64, b64), up.double().cpu())
     y1 = hip_engine.token_linear(x, w, b)
     g1 = torch.autograd.grad(y1, (x, w, b), up)
-    assert torch.equal(y0, y1)
+    close(y1.detach().cpu(), y0.detach(), 1e-5, "y")
     for a, c, name in zip(g1, g0, ("dx", "dw", "db")):
-        close(a.cpu(), c.cpu(), 1e-5, name)
+        close(a.cpu(), c, 1e-5, name)
+    y2 = hip_engine.token_linear(x, w, b)
+    g2 = torch.autograd.grad(y2, (x, w, b), up)
+    assert torch.equal(y1, y2) and all(torch.equal(a, c) for a, c in zip(g1, g2))
 
 
 def native_call_counters(monkeypatch):

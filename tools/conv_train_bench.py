@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--native-only", action="store_true", help="skip torch's convolutions (for a kernel trace of the native ones)")
     a = ap.parse_args()
     s = a.size // 4
     B = a.batch
@@ -48,10 +49,12 @@ def main():
         tf = timed(lambda: _check(lib, lib.danra_conv3x3_train_fwd(_ptr(x), _ptr(w), _ptr(y), *args), "f"))
         td = timed(lambda: _check(lib, lib.danra_conv3x3_train_dgrad(_ptr(dy), _ptr(w), _ptr(dx), *args), "d"))
         tw = timed(lambda: _check(lib, lib.danra_conv3x3_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), *args), "w"))
-        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-        ttf = timed(lambda: torch.nn.functional.conv2d(xr, wr, None, 1, 1))
-        yy = torch.nn.functional.conv2d(xr, wr, None, 1, 1)
-        ttb = timed(lambda: torch.autograd.grad(yy, (xr, wr), dy, retain_graph=True))
+        ttf = ttb = 0.0
+        if not a.native_only:
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            ttf = timed(lambda: torch.nn.functional.conv2d(xr, wr, None, 1, 1))
+            yy = torch.nn.functional.conv2d(xr, wr, None, 1, 1)
+            ttb = timed(lambda: torch.autograd.grad(yy, (xr, wr), dy, retain_graph=True))
         print(f"{name:14s} {str((B, cin, cout, hw, hw)):>22s} | {tf:8.1f} {td:6.1f} {tw:6.1f}      | {ttf:8.1f} {ttb:6.1f}")
         tot_n += count * (tf + td + tw)
         tot_t += count * (ttf + ttb)

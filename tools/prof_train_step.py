@@ -24,14 +24,14 @@ def run(size, batch, replays):
     b = dict(images=d["x"].to(dev), seasons=d["y"].to(dev), cond_images=d["cond_img"].to(dev), lsm=d["lsm_cond"].to(dev),
              topo=d["topo_cond"].to(dev))
     model = build(size, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True, fused=True)  # as tools/train_step_bench.py
     step = GraphedTrainStep(model, opt, DiffusionUtils(1000, 1e-4, 0.02, device=dev), torch.nn.MSELoss(), b)
     for _ in range(replays):
         step(**b)
         torch.cuda.synchronize()
 
 
-def summarise(path, top, sequence=False):
+def summarise(path, top, sequence=False, width=100):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the replays run the same kernel sequence: the last replay = the shortest tail that repeats the tail before it
@@ -46,7 +46,7 @@ def summarise(path, top, sequence=False):
     last = rows[cut:]
     total = defaultdict(lambda: [0, 0])
     for r in last:
-        t = total[r["Kernel_Name"][:100]]
+        t = total[r["Kernel_Name"][:width]]
         t[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         t[1] += 1
     busy = sum(v[0] for v in total.values())
@@ -73,8 +73,9 @@ if __name__ == "__main__":
     ap.add_argument("--trace")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--sequence", action="store_true")
+    ap.add_argument("--width", type=int, default=100, help="characters of a kernel name that tell kernels apart")
     a = ap.parse_args()
     if a.trace:
-        summarise(a.trace, a.top, a.sequence)
+        summarise(a.trace, a.top, a.sequence, a.width)
     else:
         run(a.size, a.batch, a.replays)
