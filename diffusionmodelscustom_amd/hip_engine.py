@@ -254,6 +254,12 @@ def attention_core_supported(tokens, n_heads):
             and tokens.shape[0] * n_heads * tokens.shape[1] < (1 << 27))
 
 
+# Token counts from which the forward product and the input gradient of a projection go through danra_linear: the tall
+# products of the 64-channel levels (8192 ... 131072 rows).  Below, the BLAS library's small kernels take 5-8 us where the
+# implicit-GEMM kernel takes 11.
+_NATIVE_LINEAR_MIN_ROWS = 4096
+
+
 class _TokenLinear(torch.autograd.Function):
     """torch.nn.functional.linear(x, weight, bias) on [..., K] fp32 CUDA tokens, forward and backward in libdanra_hip.so:
     the product and the input gradient through danra_linear (the implicit-GEMM kernel with fp32 matrix instructions; for
@@ -269,9 +275,12 @@ class _TokenLinear(torch.autograd.Function):
         x2 = x.reshape(-1, K).contiguous()
         weight = weight.contiguous()
         M = x2.shape[0]
-        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
-            _check(lib, lib.danra_linear(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), M, N, K, _stream()), "danra_linear")
+        if M >= _NATIVE_LINEAR_MIN_ROWS:
+            y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+            with torch.cuda.device(x.device):
+                _check(lib, lib.danra_linear(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), M, N, K, _stream()), "danra_linear")
+        else:
+            y = torch.nn.functional.linear(x2, weight, bias).view(x.shape[:-1] + (N,))
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         return y
@@ -287,44 +296,72 @@ class _TokenLinear(torch.autograd.Function):
         dx = None
         with torch.cuda.device(x2.device):
             if ctx.needs_input_grad[0]:
-                if lib.danra_linear_supported(M, K, N):  # dx = dy W = dy (W^T)^T
+                if M >= _NATIVE_LINEAR_MIN_ROWS and lib.danra_linear_supported(M, K, N):  # dx = dy W = dy (W^T)^T
                     dx = torch.empty(ctx.x_shape, device=x2.device, dtype=torch.float32)
                     wt = weight.t().contiguous()
                     _check(lib, lib.danra_linear(_ptr(dy2), _ptr(wt), None, _ptr(dx), M, K, N, _stream()), "danra_linear")
                 else:
                     dx = dy2.matmul(weight).view(ctx.x_shape)
-            dw = torch.empty_like(weight)
-            db = torch.empty(N, device=x2.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-            workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x2.device, dtype=torch.float32)
-            _check(lib, lib.danra_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db) if db is not None else None, M, N, K,
-                                               _ptr(workspace), _stream()), "danra_linear_wgrad")
+            if lib.danra_linear_wgrad_supported(M, N, K):
+                dw = torch.empty_like(weight)
+                db = torch.empty(N, device=x2.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+                workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x2.device, dtype=torch.float32)
+                _check(lib, lib.danra_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db) if db is not None else None, M, N, K,
+                                                   _ptr(workspace), _stream()), "danra_linear_wgrad")
+            else:
+                # wider layers (the 128 ... 512-channel attention blocks, a few thousand tokens at most): dw = dy^T x is
+                # danra_linear on the two transposed operands.  (The BLAS library behind torch.mm runs the 256 x 256 result
+                # of the 256-channel blocks as ONE 256 x 256 tile on one workgroup: 121 us per call on MI355X.)
+                if M <= 512 and lib.danra_linear_supported(N, K, M):  # (a long reduction over few output tiles stays torch's)
+                    dw = torch.empty_like(weight)
+                    dyt, xt = dy2.t().contiguous(), x2.t().contiguous()
+                    _check(lib, lib.danra_linear(_ptr(dyt), _ptr(xt), None, _ptr(dw), N, K, M, _stream()), "danra_linear")
+                else:
+                    dw = dy2.t().mm(x2)
+                db = dy2.sum(0) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
 def token_linear(x, weight, bias):
-    """``torch.nn.functional.linear`` whose weight gradient may be formed by the native library (see _TokenLinear): on
-    CUDA, float32 parameters, a layer shape the kernel has (K = 64, N = 64 / 128 / 192), with the native training kernels
-    enabled; torch's own operator otherwise."""
+    """``torch.nn.functional.linear`` through the native library (see _TokenLinear): on CUDA, float32 parameters, N and K
+    multiples of 64 (every projection of the network's attention blocks), with the native training kernels enabled;
+    torch's own operator otherwise."""
     if (native_training_kernels and x.is_cuda and weight.dtype == torch.float32 and weight.requires_grad
             and bias is not None and torch.is_grad_enabled()):
         N, K = weight.shape
         M = x.numel() // K
-        lib = load_library()
-        if lib.danra_linear_wgrad_supported(M, N, K) and lib.danra_linear_supported(M, N, K):
+        if load_library().danra_linear_supported(M, N, K) and load_library().danra_linear_supported(M, K, N):
             return _TokenLinear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
 
 
 def differentiable_self_attention(mha, tokens):
-    """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module:
-    the two projections as torch products (their weight gradients in the native library), the scaled-dot-product core
-    in the native library."""
+    """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module: the
+    two projections through token_linear, the scaled-dot-product core in the native library where it has the shape
+    (attention_core_supported: head_dim 16, the 64-channel levels) and torch's fused scaled_dot_product_attention
+    otherwise."""
     B, L, C = tokens.shape
     heads = mha.num_heads
     qkv = token_linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
-    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # made contiguous (and float32) by the core
-    attended = _AttentionCoreHD16.apply(qkv)
+    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
+    if attention_core_supported(tokens, heads):
+        attended = _AttentionCoreHD16.apply(qkv)  # (made contiguous and float32 by the core)
+    else:
+        attended = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        attended = attended.permute(0, 2, 1, 3).reshape(B, L, C)
     return token_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
+
+
+def differentiable_attention_supported(mha, tokens):
+    """True when differentiable_self_attention can take the place of `mha(tokens, tokens, tokens)`: a CUDA tensor
+    (float32; half precision under autocast) and projections the library's linear kernel has."""
+    if not (native_training_kernels and tokens.is_cuda and _native_dtype(tokens) and mha.in_proj_bias is not None
+            and mha.in_proj_weight is not None and mha.in_proj_weight.dtype == torch.float32):
+        return False
+    B, L, C = tokens.shape
+    lib = load_library()
+    return bool(lib.danra_linear_supported(B * L, 3 * C, C) and lib.danra_linear_supported(B * L, C, 3 * C)
+                and lib.danra_linear_supported(B * L, C, C))
 
 
 class _BatchNormTrain(torch.autograd.Function):

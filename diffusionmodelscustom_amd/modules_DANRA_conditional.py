@@ -56,13 +56,15 @@ class SinusoidalEmbedding(nn.Module):
 
 
 def self_attention(mha: nn.MultiheadAttention, normed: torch.Tensor):
-    """``mha(normed, normed, normed, need_weights=False)[0]`` on the differentiable path.  On a CUDA fp32 tensor whose
-    heads are 16 wide and whose token count is a multiple of 128 (the 64-channel levels, where the L x L matrices
-    of torch's composition dominate a training step's time and memory) the scaled-dot-product core runs forward and
-    backward in ``libdanra_hip.so``; the library is then mandatory.  Everything else is torch's own module."""
+    """``mha(normed, normed, normed, need_weights=False)[0]`` on the differentiable path.  On a CUDA tensor the two
+    projections run in ``libdanra_hip.so`` (the library is then mandatory), and where the heads are 16 wide and the token
+    count is a multiple of 128 (the 64-channel levels, where the L x L matrices of torch's composition dominate a training
+    step's time and memory) so does the scaled-dot-product core, forward and backward; the other levels keep torch's fused
+    core between the native projections.  Everything else is torch's own module."""
     if normed.is_cuda and mha.dropout == 0.0 and mha.batch_first and mha._qkv_same_embed_dim:
         from . import hip_engine
-        if hip_engine.attention_core_supported(normed, mha.num_heads):
+        if hip_engine.attention_core_supported(normed, mha.num_heads) or (
+                torch.is_grad_enabled() and hip_engine.differentiable_attention_supported(mha, normed)):
             return hip_engine.differentiable_self_attention(mha, normed)
     return mha(normed, normed, normed, need_weights=False)[0]
 
