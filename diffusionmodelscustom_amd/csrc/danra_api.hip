@@ -1285,6 +1285,45 @@ int danra_conv3x3_train_wgrad(const float* x, const float* dy, float* dw, int B,
     return DANRA_OK;
 }
 
+int danra_pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W) {
+    return pointwise_train_supported(kind, B, Cin, Cout, H, W) ? 1 : 0;
+}
+
+size_t danra_pointwise_train_workspace(int kind, int B, int Cin, int Cout, int H, int W) {
+    return pointwise_train_supported(kind, B, Cin, Cout, H, W)
+               ? pointwise_train_workspace_floats(kind, B, Cin, Cout, H, W) * sizeof(float) : 0;
+}
+
+static int pointwise_train_check(const void* a, const void* b, const void* c, int kind, int B, int Cin, int Cout, int H, int W) {
+    if (!a || !b || !c) return fail(DANRA_EINVAL, "null argument");
+    if (!pointwise_train_supported(kind, B, Cin, Cout, H, W))
+        return fail(DANRA_EINVAL, "kind=%d B=%d Cin=%d Cout=%d H=%d W=%d: not a layer the pointwise training kernels take "
+                    "(danra_pointwise_train_supported)", kind, B, Cin, Cout, H, W);
+    return DANRA_OK;
+}
+
+int danra_pointwise_train_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
+                              int H, int W, void* stream) {
+    RC_TRY(pointwise_train_check(x, w, y, kind, B, Cin, Cout, H, W));
+    HIP_TRY(launch_pointwise_train_fwd(kind, x, w, bias, y, B, Cin, Cout, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W,
+                                void* stream) {
+    RC_TRY(pointwise_train_check(dy, w, dx, kind, B, Cin, Cout, H, W));
+    HIP_TRY(launch_pointwise_train_dgrad(kind, dy, w, dx, B, Cin, Cout, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_pointwise_train_wgrad(int kind, const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                void* workspace, void* stream) {
+    RC_TRY(pointwise_train_check(x, dy, dw, kind, B, Cin, Cout, H, W));
+    if (!workspace) return fail(DANRA_EINVAL, "null workspace");
+    HIP_TRY(launch_pointwise_train_wgrad(kind, x, dy, dw, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_sample(danra_handle_t h, float* x, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                  int B, int H, int W, int T, const float* betas, const float* alphas, const float* alpha_hat,
                  int noise_mode, const float* noise, uint64_t seed, const int* trace_steps, int n_trace, float* trace,

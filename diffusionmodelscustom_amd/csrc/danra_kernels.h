@@ -243,6 +243,16 @@ hipError_t launch_conv3x3_train(bool dgrad, const float* in, const float* w, flo
                                 float* workspace, hipStream_t stream);
 hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
                                       float* workspace, hipStream_t stream);
+// The 1x1 stride-2 convolutions (kind 0) and the kernel-2 stride-2 transposed convolutions (kind 1) of the training step
+// on NCHW fp32 tensors with torch's weight layouts ([Cout][Cin][1][1] / [Cin][Cout][2][2]); H, W: the layer's INPUT map.
+bool pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W);
+size_t pointwise_train_workspace_floats(int kind, int B, int Cin, int Cout, int H, int W);
+hipError_t launch_pointwise_train_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                                      int Cout, int H, int W, hipStream_t stream);
+hipError_t launch_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H,
+                                        int W, hipStream_t stream);
+hipError_t launch_pointwise_train_wgrad(int kind, const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H,
+                                        int W, float* workspace, hipStream_t stream);
 __global__ void k_sum_slices(const float* __restrict__ part, float* __restrict__ out, int count4, int slices);
 
 // ---------------------------------------------------------------- weight packing

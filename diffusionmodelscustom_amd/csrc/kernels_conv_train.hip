@@ -415,4 +415,281 @@ hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw
     return sum_slabs(workspace, dw, (size_t)Cin * Cout * 9, sl, stream);
 }
 
+
+// ==================================================================================================================
+// The two "pointwise" convolutions of the training step: the 1x1 stride-2 shortcut convolutions of the BasicBlocks that
+// halve the map (torchvision's downsample[0]) and the kernel-2 stride-2 transposed convolutions of the decoder blocks.
+// Both are plain matrix products over the pixels of the COARSE grid (the smaller of the layer's two maps), with the fine
+// map addressed either at every second pixel (1x1 stride 2) or as four sub-positions (dy, dx) per coarse pixel that act
+// as four "virtual channels" per real channel (transposed convolution: v = 4 * channel + 2 * dy + dx).  One kernel forms
+// out[b][n][p] = sum_c A[n][c] in[b][c][p] for any combination of the two addressings and either orientation of the
+// weight matrix, a second one the weight gradient dW[n][c] = sum_{b,p} Y[b][n][p] X[b][c][p].
+namespace {
+
+struct PwTensor {    // how a (virtual channel, coarse pixel) of one operand is addressed in its NCHW tensor
+    int C;           // real channels
+    int H, W;        // the tensor's own map
+    int sub;         // 1: four virtual channels per real channel (pixel (2y + dy, 2x + dx) of coarse pixel (y, x))
+    int stride;      // sub == 0: pixel (stride * y, stride * x)
+};
+
+__device__ __forceinline__ size_t pw_addr(const PwTensor& t, int b, int v, int y, int x) {
+    if (t.sub) return (((size_t)b * t.C + (v >> 2)) * t.H + 2 * y + ((v >> 1) & 1)) * t.W + 2 * x + (v & 1);
+    return (((size_t)b * t.C + v) * t.H + t.stride * y) * t.W + t.stride * x;
+}
+
+constexpr int PW_KC = 32;  // (virtual) reduction channels per chunk
+constexpr int PW_LDA = PW_KC + 1;
+
+}  // namespace
+
+// out[b][n][p] (+ bias[real channel of n]) = sum_c w[n * sn + c * sc] in[b][c][p] over the coarse grid Hc x Wc.
+// Workgroup: 64 coarse pixels (any 64 consecutive ones of the flattened (image, y, x) order) x 32 output (virtual)
+// channels; waves as in k_conv3x3_train: pixel half x half of a chunk's 16 two-deep steps.
+__global__ __launch_bounds__(256) void k_pw_train(const float* __restrict__ in, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, const PwTensor ti,
+                                                  const PwTensor to, int B, int Hc, int Wc, int Cv, int Nv, int sn, int sc) {
+    __shared__ float bt[PW_KC * 64];       // [c][pixel]
+    __shared__ float at[32 * PW_LDA];      // [n][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pt = wave & 1, kh = wave >> 1;
+    const int l32 = lane & 31, kk = lane >> 5;
+    const int hw = Hc * Wc, M = B * hw;
+    const int p0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
+    // this thread's pixel of the B tile (the same for its 8 channels) and of the output
+    auto decode = [&](int p, int& b, int& y, int& x) {
+        const int q = min(p, M - 1);
+        b = q / hw;
+        const int r = q - b * hw;
+        y = r / Wc;
+        x = r - y * Wc;
+    };
+    int sb, sy, sx;
+    decode(p0 + (tid & 63), sb, sy, sx);
+    const int c_first = tid >> 6;  // channels c_first + 4 i, i = 0..7
+    // A tile: 1024 values, 4 per thread; coalesced along whichever index has stride 1
+    int asrc[4], adst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        const int n = sc == 1 ? e / PW_KC : e % 32, c = sc == 1 ? e % PW_KC : e / 32;
+        asrc[i] = (n0 + n) * sn + c * sc;
+        adst[i] = n * PW_LDA + c;
+    }
+    float breg[8], areg[4];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) breg[i] = in[pw_addr(ti, sb, c0 + c_first + 4 * i, sy, sx)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) areg[i] = w[asrc[i] + c0 * sc];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* arow = at + l32 * PW_LDA + kk;
+    const float* bcol = bt + kk * 64 + pt * 32 + l32;
+    load_chunk(0);
+    for (int c0 = 0; c0 < Cv; c0 += PW_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bt[(c_first + 4 * i) * 64 + (tid & 63)] = breg[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) at[adst[i]] = areg[i];
+        __syncthreads();
+        if (c0 + PW_KC < Cv) load_chunk(c0 + PW_KC);
+#pragma unroll
+        for (int s = 0; s < PW_KC / 4; ++s) {
+            const int pair = kh * (PW_KC / 4) + s;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * pair], bcol[2 * pair * 64], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = bt;  // 2 x 16 x 64 floats
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(pt * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const int p = p0 + pt * 32 + l32;
+    int ob, oy, ox;
+    decode(p, ob, oy, ox);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r >> 2) * 8 + kk * 4 + (r & 3);
+        float v = acc[r] + red[(pt * 16 + r) * 64 + lane];
+        if (bias) v += bias[to.sub ? (n >> 2) : n];
+        if (p < M) {
+            float* o = out + pw_addr(to, ob, n, oy, ox);
+            o[0] = v;
+            if (!to.sub && to.stride == 2) {  // the three pixels of the 2x2 cell that the strided product does not reach
+                o[1] = 0.f;
+                o[to.W] = 0.f;
+                o[to.W + 1] = 0.f;
+            }
+        }
+    }
+}
+
+// dW[n * Cv + c] = sum over images and coarse pixels of Y[b][n][p] X[b][c][p].  Workgroup: 64 x 32 values of dW x a
+// range of 64-pixel chunks (blockIdx.z: slab z); wave: half of the 64 rows x half of a chunk's pixel pairs.
+__global__ __launch_bounds__(256) void k_pw_wgrad_train(const float* __restrict__ Y, const float* __restrict__ X,
+                                                        float* __restrict__ dw, const PwTensor ty, const PwTensor tx, int B,
+                                                        int Hc, int Wc, int Nv, int Cv, int chunks_per_split) {
+    constexpr int LD = 65;
+    __shared__ float yt[64 * LD];  // [n][pixel]
+    __shared__ float xt[32 * LD];  // [c][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave & 1, kh = wave >> 1;
+    const int l32 = lane & 31, kk = lane >> 5;
+    const int hw = Hc * Wc, M = B * hw;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int n_chunks = (M + 63) / 64;
+    const int q_begin = blockIdx.z * chunks_per_split, q_end = min(n_chunks, q_begin + chunks_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int px = tid & 63, cq = tid >> 6;
+    for (int q = q_begin; q < q_end; ++q) {
+        const int p = q * 64 + px;
+        const bool ok = p < M;
+        const int pc = min(p, M - 1);
+        const int b = pc / hw, r = pc - b * hw, y = r / Wc, x = r - y * Wc;
+        float yv[16], xv[8];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yv[i] = Y[pw_addr(ty, b, n0 + cq + 4 * i, y, x)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = X[pw_addr(tx, b, c0 + cq + 4 * i, y, x)];
+        __syncthreads();  // the previous chunk has been multiplied
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yt[(cq + 4 * i) * LD + px] = ok ? yv[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xt[(cq + 4 * i) * LD + px] = ok ? xv[i] : 0.f;
+        __syncthreads();
+        const float* arow = yt + (nt * 32 + l32) * LD + kk;
+        const float* bcol = xt + l32 * LD + kk;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int pp = 2 * (kh * 16 + s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[pp], bcol[pp], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = yt;  // 2 x 16 x 64 floats
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(nt * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    float* dst = dw + (size_t)blockIdx.z * ((size_t)Nv * Cv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + nt * 32 + (r >> 2) * 8 + kk * 4 + (r & 3);
+        dst[(size_t)n * Cv + c0 + l32] = acc[r] + red[(nt * 16 + r) * 64 + lane];
+    }
+}
+
+namespace {
+
+// kind 0: nn.Conv2d(Cin, Cout, 1, stride 2) on x [B][Cin][H][W] (H, W even) -> y [B][Cout][H/2][W/2], w [Cout][Cin]
+// kind 1: nn.ConvTranspose2d(Cin, Cout, 2, stride 2) on x [B][Cin][H][W] -> y [B][Cout][2H][2W], w [Cin][Cout][2][2]
+struct PwPlan {
+    int Hc, Wc;                    // coarse grid
+    PwTensor x, y;                 // the layer's input and output tensors as operands
+    int xv, yv;                    // their virtual channel counts
+};
+
+bool pw_plan(int kind, int B, int Cin, int Cout, int H, int W, PwPlan& p) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
+    if (kind == 0) {
+        if ((H & 1) || (W & 1) || Cin % 32 || Cout % 64) return false;
+        p.Hc = H / 2; p.Wc = W / 2;
+        p.x = PwTensor{Cin, H, W, 0, 2};
+        p.y = PwTensor{Cout, H / 2, W / 2, 0, 1};
+        p.xv = Cin; p.yv = Cout;
+    } else if (kind == 1) {
+        if (Cin % 64 || Cout % 16) return false;
+        p.Hc = H; p.Wc = W;
+        p.x = PwTensor{Cin, H, W, 0, 1};
+        p.y = PwTensor{Cout, 2 * H, 2 * W, 1, 1};
+        p.xv = Cin; p.yv = 4 * Cout;
+    } else {
+        return false;
+    }
+    const long long big = (long long)B * (p.xv > p.yv ? p.xv : p.yv) * p.Hc * p.Wc;
+    return big < (1LL << 31);
+}
+
+void pw_wgrad_split(const PwPlan& p, int B, int Nv, int Cv, int& slices, int& cps) {
+    const int n_chunks = (B * p.Hc * p.Wc + 63) / 64;
+    const long tiles = (long)(Nv / 64) * (Cv / 32);
+    long s = tiles >= 128 ? 1 : (256 + tiles - 1) / tiles;
+    if (s > n_chunks) s = n_chunks;
+    if (s > 64) s = 64;
+    cps = (int)((n_chunks + s - 1) / s);
+    slices = (n_chunks + cps - 1) / cps;
+}
+
+}  // namespace
+
+bool pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W) {
+    PwPlan p;
+    return pw_plan(kind, B, Cin, Cout, H, W, p);
+}
+
+size_t pointwise_train_workspace_floats(int kind, int B, int Cin, int Cout, int H, int W) {
+    PwPlan p;
+    if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return 0;
+    // weight gradient: rows = the operand with at least 64 (virtual) channels per tile row (see launch_pointwise_wgrad_train)
+    const int Nv = kind == 0 ? p.yv : p.xv, Cv = kind == 0 ? p.xv : p.yv;
+    int sl, cps;
+    pw_wgrad_split(p, B, Nv, Cv, sl, cps);
+    return sl > 1 ? (size_t)sl * Nv * Cv : 4;
+}
+
+hipError_t launch_pointwise_train_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                                      int Cout, int H, int W, hipStream_t stream) {
+    PwPlan p;
+    if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return hipErrorInvalidValue;
+    const int M = B * p.Hc * p.Wc;
+    const dim3 grid((M + 63) / 64, p.yv / 32);
+    // kind 0: A[n = co][c = ci] = w[co * Cin + ci]; kind 1: A[n = (co, d)][c = ci] = w[ci * 4 Cout + n]
+    hipLaunchKernelGGL(k_pw_train, grid, dim3(256), 0, stream, x, w, bias, y, p.x, p.y, B, p.Hc, p.Wc, p.xv, p.yv,
+                       kind == 0 ? Cin : 1, kind == 0 ? 1 : 4 * Cout);
+    return hipGetLastError();
+}
+
+hipError_t launch_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H,
+                                        int W, hipStream_t stream) {
+    PwPlan p;
+    if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return hipErrorInvalidValue;
+    const int M = B * p.Hc * p.Wc;
+    // (kind 0: only every second pixel of every second row receives a gradient; the kernel writes the zeros between them)
+    const dim3 grid((M + 63) / 64, p.xv / 32);
+    // kind 0: A[n = ci][c = co] = w[co * Cin + ci]; kind 1: A[n = ci][c = (co, d)] = w[ci * 4 Cout + c]
+    hipLaunchKernelGGL(k_pw_train, grid, dim3(256), 0, stream, dy, w, (const float*)nullptr, dx, p.y, p.x, B, p.Hc, p.Wc, p.yv,
+                       p.xv, kind == 0 ? 1 : 4 * Cout, kind == 0 ? Cin : 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_pointwise_train_wgrad(int kind, const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H,
+                                        int W, float* workspace, hipStream_t stream) {
+    PwPlan p;
+    if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return hipErrorInvalidValue;
+    // kind 0: dw[co][ci]: rows from dy, columns from x; kind 1: dw[ci][(co, d)]: rows from x, columns from dy
+    const float* rows = kind == 0 ? dy : x;
+    const float* cols = kind == 0 ? x : dy;
+    const PwTensor tr = kind == 0 ? p.y : p.x, tc = kind == 0 ? p.x : p.y;
+    const int Nv = kind == 0 ? p.yv : p.xv, Cv = kind == 0 ? p.xv : p.yv;
+    int sl, cps;
+    pw_wgrad_split(p, B, Nv, Cv, sl, cps);
+    float* dst = sl > 1 ? workspace : dw;
+    hipLaunchKernelGGL(k_pw_wgrad_train, dim3(Cv / 32, Nv / 64, sl), dim3(256), 0, stream, rows, cols, dst, tr, tc, B, p.Hc,
+                       p.Wc, Nv, Cv, cps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || sl == 1) return e;
+    return sum_slabs(workspace, dw, (size_t)Nv * Cv, sl, stream);
+}
+
 }  // namespace danra

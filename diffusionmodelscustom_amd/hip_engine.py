@@ -76,6 +76,11 @@ _SIGNATURES = {
     "danra_linear_wgrad": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "danra_linear_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_pointwise_train_supported": (ctypes.c_int, [ctypes.c_int] * 6),
+    "danra_pointwise_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "danra_pointwise_train_fwd": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P] + [ctypes.c_int] * 5 + [_P]),
+    "danra_pointwise_train_dgrad": (ctypes.c_int, [ctypes.c_int, _P, _P, _P] + [ctypes.c_int] * 5 + [_P]),
+    "danra_pointwise_train_wgrad": (ctypes.c_int, [ctypes.c_int, _P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_conv3x3_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "danra_conv3x3_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "danra_conv3x3_train_fwd": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
@@ -506,6 +511,74 @@ class _Conv3x3Train(torch.autograd.Function):
         return dx, dw
 
 
+PW_CONV1X1_S2, PW_CONVT2X2 = 0, 1
+
+
+class _PointwiseTrain(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, 1, stride 2, bias=False) (kind 0) or nn.ConvTranspose2d(Cin, Cout, 2, stride 2) with its bias
+    (kind 1) on a contiguous NCHW fp32 CUDA tensor: forward, data gradient and weight gradient in libdanra_hip.so
+    (danra_pointwise_train_fwd / _dgrad / _wgrad); the bias gradient is torch's reduction."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight, bias, kind):
+        lib = load_library()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0] if kind == PW_CONV1X1_S2 else weight.shape[1]
+        shape = (B, Cout, H // 2, W // 2) if kind == PW_CONV1X1_S2 else (B, Cout, 2 * H, 2 * W)
+        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_pointwise_train_fwd(kind, _ptr(x), _ptr(weight), _ptr(bias), _ptr(y), B, Cin, Cout, H, W,
+                                                      _stream()), "danra_pointwise_train_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.kind, ctx.Cout, ctx.has_bias = kind, Cout, bias is not None
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        kind, Cout = ctx.kind, ctx.Cout
+        B, Cin, H, W = x.shape
+        dy = _f32(dy, "dy")
+        dx = dw = db = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W,
+                                                            _stream()), "danra_pointwise_train_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                ws = torch.empty(max(lib.danra_pointwise_train_workspace(kind, B, Cin, Cout, H, W) // 4, 1), device=x.device,
+                                 dtype=torch.float32)
+                _check(lib, lib.danra_pointwise_train_wgrad(kind, _ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
+                                                            _stream()), "danra_pointwise_train_wgrad")
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dy.sum((0, 2, 3))
+        return dx, dw, db, None
+
+
+def _pointwise_ok(x, weight):
+    return (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
+            and _native_dtype(x) and weight.dtype == torch.float32 and (x.requires_grad or weight.requires_grad))
+
+
+def conv_transpose2d(convt, x):
+    """``convt(x)`` for an nn.ConvTranspose2d.  A kernel-2, stride-2, unpadded, ungrouped one on a 4-D CUDA tensor with
+    gradients enabled - a decoder block's up-sampling in the training step - runs forward and backward in the native library
+    where it has the shape (danra_pointwise_train_supported); everything else is the module itself."""
+    if (type(convt) is torch.nn.ConvTranspose2d and convt.kernel_size == (2, 2) and convt.stride == (2, 2)
+            and convt.padding == (0, 0) and convt.output_padding == (0, 0) and convt.dilation == (1, 1) and convt.groups == 1
+            and _pointwise_ok(x, convt.weight)):
+        B, Cin, H, W = x.shape
+        if load_library().danra_pointwise_train_supported(PW_CONVT2X2, B, Cin, convt.out_channels, H, W):
+            return _PointwiseTrain.apply(x, convt.weight, convt.bias, PW_CONVT2X2)
+    return convt(x)
+
+
 def conv2d(conv, x):
     """``conv(x)`` for an nn.Conv2d.  A 3x3, stride-1, padding-1, ungrouped convolution on a 4-D CUDA tensor (float32; half
     precision under autocast) with gradients enabled - the training step - runs forward and backward in the native library
@@ -519,6 +592,11 @@ def conv2d(conv, x):
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    if (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and _pointwise_ok(x, conv.weight)):
+        B, Cin, H, W = x.shape
+        if load_library().danra_pointwise_train_supported(PW_CONV1X1_S2, B, Cin, conv.out_channels, H, W):
+            return _PointwiseTrain.apply(x, conv.weight, None, PW_CONV1X1_S2)
     return conv(x)
 
 

@@ -224,12 +224,12 @@ class DecoderBlock(nn.Module):
         return 'feature maps must be of same shape'
 
     def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
-        up = self.transpose(fmap)
-        if up.is_cuda:  # the two norms run forward and backward in the native library where it has them
-            from .hip_engine import conv2d, instance_norm
+        if fmap.is_cuda:  # up-sampling, the two norms and the convolution run in the native library where it has them
+            from .hip_engine import conv2d, conv_transpose2d, instance_norm
+            up = conv_transpose2d(self.transpose, fmap)
             out = instance_norm(self.instance_norm2, conv2d(self.conv, instance_norm(self.instance_norm1, up)))
         else:
-            out = self.instance_norm2(self.conv(self.instance_norm1(up)))
+            out = self.instance_norm2(self.conv(self.instance_norm1(self.transpose(fmap))))
         if out.requires_grad:
             out = _DenseGradient.apply(out)
         if torch.is_tensor(prev_fmap):

@@ -50,7 +50,7 @@ class BasicBlock(nn.Module):
         if self.downsample is None:
             shortcut = x
         elif isinstance(self.downsample, nn.Sequential) and len(self.downsample) == 2:
-            shortcut = norm_relu(self.downsample[1], None, self.downsample[0](x))
+            shortcut = norm_relu(self.downsample[1], None, conv2d(self.downsample[0], x))
         else:
             shortcut = self.downsample(x)
         y = norm_relu(self.bn1, self.relu, conv2d(self.conv1, x))

@@ -232,6 +232,27 @@ int danra_conv3x3_train_dgrad(const float* dy_dev, const float* w_dev, float* dx
 int danra_conv3x3_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
                               void* workspace_dev, void* stream);
 
+/* The two stride-2 "pointwise" convolutions of the training step (training_DANRA_conditional.py:962-984), forward, data
+ * gradient and weight gradient, on contiguous NCHW fp32 tensors with torch's weight layouts; H, W = the layer's INPUT map:
+ *   kind DANRA_PW_CONV1X1_S2 (0): nn.Conv2d(Cin, Cout, 1, stride 2, bias=False), the shortcut of a BasicBlock that halves
+ *     the map (torchvision's downsample[0], built by modules_DANRA_conditional.py:154); w [Cout][Cin][1][1];
+ *     y [B][Cout][H/2][W/2].  Supported: H, W even, Cin a multiple of 32, Cout of 64.
+ *   kind DANRA_PW_CONVT2X2 (1): nn.ConvTranspose2d(Cin, Cout, 2, stride 2), the up-sampling of a decoder block
+ *     (modules_DANRA_conditional.py:408-411); w [Cin][Cout][2][2]; y [B][Cout][2H][2W]; `bias_dev` ([Cout] or NULL) is added
+ *     by the forward call.  Supported: Cin a multiple of 64, Cout of 16.
+ * The weight gradient takes danra_pointwise_train_workspace(...) bytes of the caller's device memory (slabs added in a fixed
+ * order); nothing is allocated. */
+#define DANRA_PW_CONV1X1_S2 0
+#define DANRA_PW_CONVT2X2 1
+int danra_pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W);
+size_t danra_pointwise_train_workspace(int kind, int B, int Cin, int Cout, int H, int W);
+int danra_pointwise_train_fwd(int kind, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B,
+                              int Cin, int Cout, int H, int W, void* stream);
+int danra_pointwise_train_dgrad(int kind, const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int Cout,
+                                int H, int W, void* stream);
+int danra_pointwise_train_wgrad(int kind, const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout,
+                                int H, int W, void* workspace_dev, void* stream);
+
 /* Batch sharding of the in-kernel noise (no counterpart in the reference, which samples on one device): the calls
  * to danra_sample / danra_sample_guided that follow treat their image 0 as image `first_image` of a larger batch:
  * with DANRA_NOISE_PHILOX the draw for element e of local image b at a timestep is that of global element

@@ -222,8 +222,8 @@ def test_training_step_gradients(builder, monkeypatch):
     """One training step's loss and parameter gradients (train mode: batch statistics in BatchNorm) against a float64
     evaluation of the same step on the CPU, for three float32 evaluations on the GPU: the 64-channel attention cores in
     the native library with their default split-operand fp16 products, the same kernels with fp32 matrix instructions
-    only, and torch's own attention.  Bars, per evaluation: the median over the parameter tensors of the rms gradient
-    error (relative to the tensor's rms) at most 2e-4, and no tensor further than 3e-2.
+    only, and torch's own attention core.  Bars, per evaluation: the median over the parameter tensors of the rms gradient
+    error (relative to the tensor's rms) at most 2e-4 (1e-3 for the evaluation with torch's core), and no tensor further than 3e-2.
 
     Why eight images: the gradient of this piecewise-linear network is discontinuous wherever a ReLU input crosses
     zero, and of its few million ReLU inputs a handful always sit within float32 rounding of zero, so two correct float32
@@ -288,7 +288,10 @@ def test_training_step_gradients(builder, monkeypatch):
     print(text)
     for name, (loss_err, err, tensor, median) in report.items():
         assert loss_err <= 2e-6, f"{name}: loss off by {loss_err:.2e} relative to float64 [{text}]"
-        assert median <= 2e-4, f"{name}: median gradient error {median:.3e} of the tensors' rms [{text}]"
+        # (torch's fused scaled-dot-product attention is the less exact of the three cores: with it a flip in the second
+        # layer has been seen to carry 2.0e-4 into most tensors; it is here for comparison, its bar is 1e-3)
+        bar = 1e-3 if name.startswith("torch") else 2e-4
+        assert median <= bar, f"{name}: median gradient error {median:.3e} of the tensors' rms [{text}]"
         assert err <= 3e-2, f"{name}: gradient of {tensor} is {err:.3e} of its rms away from float64 [{text}]"
 
 
@@ -485,7 +488,8 @@ def test_token_linear_equals_torch_linear():
 def native_call_counters(monkeypatch):
     names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
              "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
-             "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad")
+             "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
+             "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
@@ -496,7 +500,9 @@ def native_call_counters(monkeypatch):
 EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 20,
                          "danra_batchnorm_train_bwd": 20, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
                          "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
-                         "danra_conv3x3_train_wgrad": 17}
+                         "danra_conv3x3_train_wgrad": 17,
+                         # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
+                         "danra_pointwise_train_fwd": 8, "danra_pointwise_train_dgrad": 8, "danra_pointwise_train_wgrad": 8}
 
 
 def test_train_mode_network_uses_the_native_kernels(monkeypatch):

@@ -108,3 +108,87 @@ def test_conv2d_function_equals_the_torch_module(monkeypatch):
     hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 1).to(DEV), x)   # stride 2: the module
     hip_engine.conv2d(torch.nn.Conv2d(128, 1, 3, 1, 1).to(DEV), x)    # one output channel: the module
     assert calls == []
+
+
+# the 1x1 stride-2 shortcut convolutions (kind 0) and the kernel-2 stride-2 transposed convolutions (kind 1) of the 64x64
+# network, odd batch sizes (the last 64-pixel chunk is cut), and the final block's transposed convolution at batch 8
+POINTWISE = [
+    (0, 3, 64, 128, 16, 16), (0, 5, 128, 256, 8, 8), (0, 7, 256, 512, 4, 4), (0, 32, 64, 128, 16, 16),
+    (1, 5, 512, 512, 2, 2), (1, 3, 256, 256, 4, 4), (1, 3, 128, 128, 8, 8), (1, 2, 64, 64, 16, 16), (1, 8, 64, 64, 32, 32),
+    (1, 32, 512, 512, 2, 2), (1, 2, 64, 16, 8, 4),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H,W", POINTWISE)
+def test_pointwise_kernels_match_float64(kind, B, Cin, Cout, H, W):
+    lib = hip_engine.load_library()
+    assert lib.danra_pointwise_train_supported(kind, B, Cin, Cout, H, W)
+    g = torch.Generator().manual_seed(kind * 7 + B * 1000 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    if kind == 0:
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+        bias = None
+        ref = lambda xx, ww, bb: torch.nn.functional.conv2d(xx, ww, None, 2, 0)
+    else:
+        w = torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = lambda xx, ww, bb: torch.nn.functional.conv_transpose2d(xx, ww, bb, 2, 0)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = ref(xd, wd, None if bias is None else bias.double())
+    dy = torch.randn(want.shape, generator=g)
+    want.backward(dy.double())
+
+    def run():
+        xg, wg, dyg = x.to(DEV), w.to(DEV), dy.to(DEV)
+        bg = None if bias is None else bias.to(DEV)
+        y = torch.empty(want.shape, device=DEV)
+        dx, dw = torch.full_like(xg, float("nan")), torch.empty_like(wg)
+        ws = torch.empty(max(lib.danra_pointwise_train_workspace(kind, B, Cin, Cout, H, W) // 4, 1), device=DEV)
+        _check(lib, lib.danra_pointwise_train_fwd(kind, _ptr(xg), _ptr(wg), _ptr(bg), _ptr(y), B, Cin, Cout, H, W, _stream()), "fwd")
+        _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dyg), _ptr(wg), _ptr(dx), B, Cin, Cout, H, W, _stream()), "dgrad")
+        _check(lib, lib.danra_pointwise_train_wgrad(kind, _ptr(xg), _ptr(dyg), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws), _stream()),
+               "wgrad")
+        torch.cuda.synchronize()
+        return y.cpu(), dx.cpu(), dw.cpu()
+
+    y, dx, dw = run()
+    close(y, want.detach(), "forward")
+    close(dx, xd.grad, "data gradient")
+    close(dw, wd.grad, "weight gradient")
+    for a, b, what in zip((y, dx, dw), run(), ("forward", "data gradient", "weight gradient")):
+        assert torch.equal(a, b), f"{what}: two calls differ"
+
+
+def test_pointwise_modules_equal_torch(monkeypatch):
+    """hip_engine.conv2d on a 1x1 stride-2 nn.Conv2d and hip_engine.conv_transpose2d on a decoder block's nn.ConvTranspose2d
+    (with its bias): outputs and every gradient against the modules in float64; other modules are left to torch."""
+    torch.manual_seed(4)
+    lib = hip_engine.load_library()
+    calls = []
+    for name in ("danra_pointwise_train_fwd", "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad"):
+        real = getattr(lib, name)
+        monkeypatch.setattr(lib, name, lambda *a, _r=real, _n=name: (calls.append(_n), _r(*a))[1])
+    for mod, fn, shape in ((torch.nn.Conv2d(64, 128, 1, 2, bias=False), hip_engine.conv2d, (4, 64, 16, 16)),
+                           (torch.nn.ConvTranspose2d(128, 128, 2, 2), hip_engine.conv_transpose2d, (4, 128, 8, 8))):
+        mod = mod.to(DEV)
+        x = torch.randn(*shape, device=DEV, requires_grad=True)
+        del calls[:]
+        y = fn(mod, x)
+        dy = torch.randn_like(y)
+        grads = torch.autograd.grad(y, [x] + list(mod.parameters()), dy)
+        assert sorted(calls) == ["danra_pointwise_train_dgrad", "danra_pointwise_train_fwd", "danra_pointwise_train_wgrad"]
+        mod64 = type(mod)(mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, bias=mod.bias is not None).double()
+        mod64.load_state_dict({k: v.double().cpu() for k, v in mod.state_dict().items()})
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        y64 = mod64(x64)
+        want = torch.autograd.grad(y64, [x64] + list(mod64.parameters()), dy.double().cpu())
+        close(y.detach().cpu(), y64.detach(), "output")
+        for a, b in zip(grads, want):
+            close(a.cpu(), b, "gradient")
+    del calls[:]
+    x = torch.randn(2, 64, 16, 16, device=DEV, requires_grad=True)
+    hip_engine.conv2d(torch.nn.Conv2d(64, 128, 1, 1, bias=False).to(DEV), x)            # stride 1: the module
+    hip_engine.conv_transpose2d(torch.nn.ConvTranspose2d(64, 64, 4, 2, 1).to(DEV), x)   # kernel 4: the module
+    with torch.no_grad():
+        hip_engine.conv_transpose2d(torch.nn.ConvTranspose2d(64, 64, 2, 2).to(DEV), x)  # no gradient: the module
+    assert calls == []
