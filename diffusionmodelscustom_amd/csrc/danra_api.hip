@@ -1285,6 +1285,35 @@ int danra_conv3x3_train_wgrad(const float* x, const float* dy, float* dw, int B,
     return DANRA_OK;
 }
 
+int danra_ln_tokens_supported(int B, int C, int L) { return ln_tokens_supported(B, C, L) ? 1 : 0; }
+
+size_t danra_ln_tokens_workspace(int B, int C, int L) { return ln_tokens_workspace_floats(B, C, L) * sizeof(float); }
+
+int danra_ln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* normed, float* mean, float* rstd, int B,
+                        int C, int L, float eps, void* stream) {
+    if (!x || !gamma || !beta || !normed || !mean || !rstd) return fail(DANRA_EINVAL, "null argument");
+    if (!ln_tokens_supported(B, C, L)) return fail(DANRA_EINVAL, "B=%d C=%d L=%d: not supported (danra_ln_tokens_supported)", B, C, L);
+    HIP_TRY(launch_ln_tokens_fwd(x, gamma, beta, normed, mean, rstd, B, C, L, eps, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_ln_tokens_bwd(const float* dn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                        float* dgamma_dbeta, int B, int C, int L, void* workspace, void* stream) {
+    if (!dn || !x || !mean || !rstd || !gamma || !dx || !dgamma_dbeta || !workspace) return fail(DANRA_EINVAL, "null argument");
+    if (!ln_tokens_supported(B, C, L)) return fail(DANRA_EINVAL, "B=%d C=%d L=%d: not supported (danra_ln_tokens_supported)", B, C, L);
+    HIP_TRY(launch_ln_tokens_bwd(dn, x, mean, rstd, gamma, dx, dgamma_dbeta, B, C, L, static_cast<float*>(workspace),
+                                 (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_tokens_to_nchw_add(const float* tokens, const float* add, float* out, int B, int C, int L, void* stream) {
+    if (!tokens || !out) return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || (long long)B * C * L >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d L=%d: positive sizes, B <= 65535, fewer than 2^31 elements", B, C, L);
+    HIP_TRY(launch_tokens_to_nchw_add(tokens, add, out, B, C, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W) {
     return pointwise_train_supported(kind, B, Cin, Cout, H, W) ? 1 : 0;
 }

@@ -243,6 +243,15 @@ hipError_t launch_conv3x3_train(bool dgrad, const float* in, const float* w, flo
                                 float* workspace, hipStream_t stream);
 hipError_t launch_conv3x3_wgrad_train(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
                                       float* workspace, hipStream_t stream);
+// Entry and exit of an attention block in the training step (kernels_train.hip): NCHW map -> LayerNorm'ed tokens and its
+// backward pass (dgamma_dbeta: [2][C]; workspace: ln_tokens_workspace_floats floats), tokens (+ NCHW residual) -> NCHW map.
+bool ln_tokens_supported(int B, int C, int L);
+size_t ln_tokens_workspace_floats(int B, int C, int L);
+hipError_t launch_ln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* normed, float* mean, float* rstd,
+                                int B, int C, int L, float eps, hipStream_t stream);
+hipError_t launch_ln_tokens_bwd(const float* dn, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                float* dx, float* dgamma_dbeta, int B, int C, int L, float* workspace, hipStream_t stream);
+hipError_t launch_tokens_to_nchw_add(const float* tokens, const float* add, float* out, int B, int C, int L, hipStream_t stream);
 // The 1x1 stride-2 convolutions (kind 0) and the kernel-2 stride-2 transposed convolutions (kind 1) of the training step
 // on NCHW fp32 tensors with torch's weight layouts ([Cout][Cin][1][1] / [Cin][Cout][2][2]); H, W: the layer's INPUT map.
 bool pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W);

@@ -424,4 +424,186 @@ hipError_t launch_linear_wgrad(const float* dy, const float* x, float* dw, float
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The entry of an attention block in the training step (ImageSelfAttention.forward, modules_DANRA_conditional.py:93-98):
+// NCHW feature map -> tokens [B][L][C] -> LayerNorm over C, as ONE kernel in either direction, so that neither the
+// transposed copy of the map nor a strided view of it exists.  A workgroup owns TL tokens of one image (TL = 32, or all L
+// tokens of a smaller map): the map's values for those tokens go through an LDS tile [TL][C + 1] (read along the pixels,
+// written along the channels).
+//
+// forward : normed[b][l][c] = (x[b][c][l] - mean) * rstd * gamma[c] + beta[c];  mean / rstd [B*L] are kept.
+// backward: dx[b][c][l] = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dn * gamma;
+//           part[tile][0][c] = sum_t dn * xhat, part[tile][1][c] = sum_t dn   (summed over the tiles by k_sum_slices)
+namespace {
+struct LnTokGeom {
+    int C, L, TL, tiles_per_img;
+};
+bool ln_tok_geom(int B, int C, int L, LnTokGeom& g) {
+    if (B <= 0 || C <= 0 || L <= 0 || C % 4 || C > 512) return false;
+    if (L % 32 == 0) g.TL = 32;
+    else if (L >= 4 && L < 32 && (L & (L - 1)) == 0) g.TL = L;  // (a token's channel sums stay inside one wave)
+    else return false;
+    if ((size_t)2 * g.TL * (C + 1) * sizeof(float) > 64 * 1024) return false;
+    g.C = C; g.L = L; g.tiles_per_img = L / g.TL;
+    return (long long)B * C * L < (1LL << 31);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_ln_tokens_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ normed,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       const LnTokGeom g, float eps) {
+    extern __shared__ float lds[];
+    const int C = g.C, L = g.L, TL = g.TL, LD = C + 1;
+    float* tile = lds;               // [TL][C + 1]
+    float* stat = lds + TL * LD;     // [TL][2]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / g.tiles_per_img, l0 = (blockIdx.x - b * g.tiles_per_img) * TL;
+    const float* xb = x + (size_t)b * C * L + l0;
+    for (int e = tid; e < TL * C; e += 256) {
+        const int c = e / TL, t = e - c * TL;
+        tile[t * LD + c] = xb[(size_t)c * L + t];
+    }
+    __syncthreads();
+    const int TPT = 256 / TL;  // threads per token: consecutive lanes of one wave
+    const int t = tid / TPT, j = tid - t * TPT;
+    float s = 0.f;
+    for (int c = j; c < C; c += TPT) s += tile[t * LD + c];
+    for (int o = 1; o < TPT; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = j; c < C; c += TPT) {
+        const float d = tile[t * LD + c] - mean;
+        q += d * d;
+    }
+    for (int o = 1; o < TPT; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (j == 0) {
+        stat[2 * t] = mean;
+        stat[2 * t + 1] = rstd;
+        mean_out[(size_t)b * L + l0 + t] = mean;
+        rstd_out[(size_t)b * L + l0 + t] = rstd;
+    }
+    __syncthreads();
+    float* nb = normed + ((size_t)b * L + l0) * C;
+    for (int e = tid; e < TL * C; e += 256) {
+        const int tt = e / C, c = e - tt * C;
+        nb[e] = (tile[tt * LD + c] - stat[2 * tt]) * stat[2 * tt + 1] * gamma[c] + beta[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ln_tokens_bwd(const float* __restrict__ dn, const float* __restrict__ x,
+                                                       const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                       const float* __restrict__ gamma, float* __restrict__ dx,
+                                                       float* __restrict__ part, const LnTokGeom g) {
+    extern __shared__ float lds[];
+    const int C = g.C, L = g.L, TL = g.TL, LD = C + 1;
+    float* xh = lds;                 // [TL][C + 1]: xhat, then dx
+    float* dt = lds + TL * LD;       // [TL][C + 1]: dn
+    __shared__ float stat[32][2];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / g.tiles_per_img, l0 = (blockIdx.x - b * g.tiles_per_img) * TL;
+    const float* xb = x + (size_t)b * C * L + l0;
+    const float* mb = mean_in + (size_t)b * L + l0;
+    const float* rb = rstd_in + (size_t)b * L + l0;
+    for (int e = tid; e < TL * C; e += 256) {
+        const int c = e / TL, t = e - c * TL;
+        xh[t * LD + c] = (xb[(size_t)c * L + t] - mb[t]) * rb[t];
+    }
+    const float* db = dn + ((size_t)b * L + l0) * C;
+    for (int e = tid; e < TL * C; e += 256) {
+        const int tt = e / C, c = e - tt * C;
+        dt[tt * LD + c] = db[e];
+    }
+    __syncthreads();
+    // per-channel sums over this tile's tokens (fixed order)
+    for (int c = tid; c < C; c += 256) {
+        float dg = 0.f, dbv = 0.f;
+        for (int tt = 0; tt < TL; ++tt) {
+            const float d = dt[tt * LD + c];
+            dg += d * xh[tt * LD + c];
+            dbv += d;
+        }
+        part[(size_t)blockIdx.x * 2 * C + c] = dg;
+        part[(size_t)blockIdx.x * 2 * C + C + c] = dbv;
+    }
+    // per-token sums over the channels
+    const int TPT = 256 / TL;
+    const int t = tid / TPT, j = tid - t * TPT;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = j; c < C; c += TPT) {
+        const float gv = dt[t * LD + c] * gamma[c];
+        s1 += gv;
+        s2 += gv * xh[t * LD + c];
+    }
+    for (int o = 1; o < TPT; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (j == 0) {
+        stat[t][0] = s1 / (float)C;
+        stat[t][1] = s2 / (float)C;
+    }
+    __syncthreads();
+    float* dxb = dx + (size_t)b * C * L + l0;
+    for (int e = tid; e < TL * C; e += 256) {
+        const int c = e / TL, tt = e - c * TL;
+        const float gv = dt[tt * LD + c] * gamma[c];
+        dxb[(size_t)c * L + tt] = rb[tt] * (gv - stat[tt][0] - xh[tt * LD + c] * stat[tt][1]);
+    }
+}
+
+// dst[b][c][l] = add[b][c][l] + src[b][l][c]: the exit of an attention block (tokens + residual back to NCHW).
+__global__ __launch_bounds__(256) void k_tokens_to_nchw_add(const float* __restrict__ src, const float* __restrict__ add,
+                                                            float* __restrict__ dst, int L, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int l0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* s = src + (size_t)b * L * C;
+    for (int i = ty; i < 32; i += 8)
+        if (l0 + i < L && c0 + tx < C) tile[i][tx] = s[(size_t)(l0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && l0 + tx < L) {
+            const size_t o = ((size_t)b * C + c0 + i) * L + l0 + tx;
+            dst[o] = (add ? add[o] : 0.f) + tile[tx][i];
+        }
+}
+
+bool ln_tokens_supported(int B, int C, int L) {
+    LnTokGeom g;
+    return ln_tok_geom(B, C, L, g);
+}
+size_t ln_tokens_workspace_floats(int B, int C, int L) {
+    LnTokGeom g;
+    return ln_tok_geom(B, C, L, g) ? (size_t)B * g.tiles_per_img * 2 * C : 0;
+}
+hipError_t launch_ln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* normed, float* mean, float* rstd,
+                                int B, int C, int L, float eps, hipStream_t stream) {
+    LnTokGeom g;
+    if (!ln_tok_geom(B, C, L, g)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)g.TL * (C + 1) + 2 * g.TL) * sizeof(float);
+    hipLaunchKernelGGL(k_ln_tokens_fwd, dim3(B * g.tiles_per_img), dim3(256), lds, stream, x, gamma, beta, normed, mean, rstd, g,
+                       eps);
+    return hipGetLastError();
+}
+hipError_t launch_ln_tokens_bwd(const float* dn, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                float* dx, float* dgamma_dbeta, int B, int C, int L, float* workspace, hipStream_t stream) {
+    LnTokGeom g;
+    if (!ln_tok_geom(B, C, L, g)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * g.TL * (C + 1) * sizeof(float);
+    const int tiles = B * g.tiles_per_img;
+    hipLaunchKernelGGL(k_ln_tokens_bwd, dim3(tiles), dim3(256), lds, stream, dn, x, mean, rstd, gamma, dx, workspace, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sum_slices, dim3((2 * C / 4 + 31) / 32), dim3(256), 0, stream, workspace, dgamma_dbeta, 2 * C / 4, tiles);
+    return hipGetLastError();
+}
+hipError_t launch_tokens_to_nchw_add(const float* tokens, const float* add, float* out, int B, int C, int L, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tokens_to_nchw_add, dim3((C + 31) / 32, (L + 31) / 32, B), dim3(256), 0, stream, tokens, add, out, L, C);
+    return hipGetLastError();
+}
+
 }  // namespace danra

@@ -76,6 +76,11 @@ _SIGNATURES = {
     "danra_linear_wgrad": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "danra_linear_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_ln_tokens_supported": (ctypes.c_int, [ctypes.c_int] * 3),
+    "danra_ln_tokens_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "danra_ln_tokens_fwd": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, _P]),
+    "danra_ln_tokens_bwd": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 3 + [_P, _P]),
+    "danra_tokens_to_nchw_add": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 3 + [_P]),
     "danra_pointwise_train_supported": (ctypes.c_int, [ctypes.c_int] * 6),
     "danra_pointwise_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "danra_pointwise_train_fwd": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P] + [ctypes.c_int] * 5 + [_P]),
@@ -509,6 +514,93 @@ class _Conv3x3Train(torch.autograd.Function):
                 _check(lib, lib.danra_conv3x3_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
                                                           _stream()), "danra_conv3x3_train_wgrad")
         return dx, dw
+
+
+class _LNTokens(torch.autograd.Function):
+    """x [B, C, H, W] -> LayerNorm_C(x.view(B, C, H*W).transpose(1, 2)) as [B, H*W, C]: the entry of an attention block,
+    forward and backward as one kernel each in libdanra_hip.so (danra_ln_tokens_fwd / _bwd): no transposed copy of the map."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, gamma, beta, eps):
+        lib = load_library()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        L = H * W
+        normed = torch.empty((B, L, C), device=x.device, dtype=torch.float32)
+        mean = torch.empty(B * L, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_ln_tokens_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(normed), _ptr(mean), _ptr(rstd), B, C, L,
+                                                ctypes.c_float(eps), _stream()), "danra_ln_tokens_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return normed
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dn):
+        lib = load_library()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        L = H * W
+        dn = _f32(dn, "dn")
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(lib.danra_ln_tokens_workspace(B, C, L) // 4, 1), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_ln_tokens_bwd(_ptr(dn), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dgb), B, C,
+                                                L, _ptr(ws), _stream()), "danra_ln_tokens_bwd")
+        return dx, dgb[0], dgb[1], None
+
+
+class _TokensResidualNCHW(torch.autograd.Function):
+    """(tokens [B, L, C], x [B, C, H, W]) -> x + tokens.transpose(1, 2).view_as(x): the exit of an attention block as one
+    kernel (danra_tokens_to_nchw_add); the backward pass is one transposition (danra_nchw_to_nhwc)."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, tokens, x):
+        lib = load_library()
+        tokens, x = tokens.contiguous(), x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_tokens_to_nchw_add(_ptr(tokens), _ptr(x), _ptr(out), B, C, H * W, _stream()),
+                   "danra_tokens_to_nchw_add")
+        return out
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        lib = load_library()
+        dout = _f32(dout, "dout")
+        B, C, H, W = dout.shape
+        dtok = torch.empty((B, H * W, C), device=dout.device, dtype=torch.float32)
+        with torch.cuda.device(dout.device):
+            _check(lib, lib.danra_nchw_to_nhwc(_ptr(dout), _ptr(dtok), B, C, H * W, _stream()), "danra_nchw_to_nhwc")
+        return dtok, dout
+
+
+def attention_block_supported(layernorm, x):
+    """True when the entry and exit of an attention block on the NCHW map `x` can run in the native library: the training
+    step on a CUDA tensor (float32; half precision under autocast), an affine nn.LayerNorm over the channels, a token and
+    channel count the kernels have (danra_ln_tokens_supported), a batch the transposition's grid takes."""
+    if not (native_training_kernels and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4 and _native_dtype(x)
+            and type(layernorm) is torch.nn.LayerNorm and layernorm.elementwise_affine and layernorm.bias is not None
+            and layernorm.weight.dtype == torch.float32 and tuple(layernorm.normalized_shape) == (x.shape[1],)
+            and x.shape[0] <= 65535):
+        return False
+    return bool(load_library().danra_ln_tokens_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]))
+
+
+def ln_tokens(layernorm, x):
+    """layernorm(x.reshape(B, C, H*W).permute(0, 2, 1)) through the native kernel (see attention_block_supported)."""
+    return _LNTokens.apply(x, layernorm.weight, layernorm.bias, float(layernorm.eps))
+
+
+def tokens_residual_nchw(tokens, x):
+    """(tokens + x.reshape(B, C, H*W).permute(0, 2, 1)).permute(0, 2, 1).reshape_as(x) through the native kernel."""
+    return _TokensResidualNCHW.apply(tokens, x)
 
 
 PW_CONV1X1_S2, PW_CONVT2X2 = 0, 1

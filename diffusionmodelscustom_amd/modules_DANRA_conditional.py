@@ -82,6 +82,11 @@ class ImageSelfAttention(nn.Module):
 
     def forward(self, x: torch.Tensor):
         _, C, H, W = x.shape
+        if x.is_cuda:  # training step: entry (map -> normalised tokens) and exit (tokens + residual -> map) as one kernel each
+            from . import hip_engine
+            if hip_engine.attention_block_supported(self.layernorm, x):
+                normed = hip_engine.ln_tokens(self.layernorm, x)
+                return hip_engine.tokens_residual_nchw(self_attention(self.attention, normed), x)
         tokens = x.reshape(-1, C, H * W).permute(0, 2, 1)
         normed = self.layernorm(tokens)
         attended = self_attention(self.attention, normed)

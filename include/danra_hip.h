@@ -232,6 +232,24 @@ int danra_conv3x3_train_dgrad(const float* dy_dev, const float* w_dev, float* dx
 int danra_conv3x3_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
                               void* workspace_dev, void* stream);
 
+/* Entry and exit of ImageSelfAttention.forward (modules_DANRA_conditional.py:93-110) in the training step, on the NCHW map the
+ * block receives and returns (L = H*W tokens of C channels):
+ *   danra_ln_tokens_fwd : normed[b][l][c] = LayerNorm_C(x[b][.][l])[c] * gamma[c] + beta[c]   (x.view(B, C, L).swapaxes(1, 2)
+ *                         followed by nn.LayerNorm(C), :93-97); mean / rstd: [B*L], kept for the backward pass;
+ *   danra_ln_tokens_bwd : dx (NCHW), and dgamma_dbeta [2][C], from the gradient of `normed`; workspace:
+ *                         danra_ln_tokens_workspace(B, C, L) bytes of the caller's device memory;
+ *   danra_tokens_to_nchw_add : out[b][c][l] = add[b][c][l] + tokens[b][l][c]   (the residual and the way back, :107-110;
+ *                         add may be NULL).  Its backward pass is danra_nchw_to_nhwc of the incoming gradient.
+ * Supported (danra_ln_tokens_supported): C a multiple of 4, at most 512; L a multiple of 32, or 4, 8 or 16. */
+int danra_ln_tokens_supported(int B, int C, int L);
+size_t danra_ln_tokens_workspace(int B, int C, int L);
+int danra_ln_tokens_fwd(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* normed_dev, float* mean_dev,
+                        float* rstd_dev, int B, int C, int L, float eps, void* stream);
+int danra_ln_tokens_bwd(const float* dn_dev, const float* x_dev, const float* mean_dev, const float* rstd_dev,
+                        const float* gamma_dev, float* dx_dev, float* dgamma_dbeta_dev, int B, int C, int L, void* workspace_dev,
+                        void* stream);
+int danra_tokens_to_nchw_add(const float* tokens_dev, const float* add_dev, float* out_dev, int B, int C, int L, void* stream);
+
 /* The two stride-2 "pointwise" convolutions of the training step (training_DANRA_conditional.py:962-984), forward, data
  * gradient and weight gradient, on contiguous NCHW fp32 tensors with torch's weight layouts; H, W = the layer's INPUT map:
  *   kind DANRA_PW_CONV1X1_S2 (0): nn.Conv2d(Cin, Cout, 1, stride 2, bias=False), the shortcut of a BasicBlock that halves

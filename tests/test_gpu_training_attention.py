@@ -485,11 +485,49 @@ def test_token_linear_equals_torch_linear():
     assert torch.equal(y1, y2) and all(torch.equal(a, c) for a, c in zip(g1, g2))
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 64, 32, 32), (2, 64, 16, 16), (3, 128, 8, 8), (5, 256, 4, 4), (7, 512, 2, 2),
+                                     (2, 64, 64, 64)])
+def test_attention_block_entry_and_exit_match_float64(B, C, H, W):
+    """hip_engine.ln_tokens (map -> LayerNorm'ed tokens) and hip_engine.tokens_residual_nchw (tokens + residual -> map)
+    against the reference's composition (modules_DANRA_conditional.py:93-110: reshape, permute, nn.LayerNorm, add, permute
+    back) in float64: outputs and every gradient within 1e-5, bit-identical between two calls."""
+    torch.manual_seed(B + C)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    x = (torch.randn(B, C, H, W, device=DEV) * 3 + 0.5).requires_grad_(True)
+    tok = torch.randn(B, H * W, C, device=DEV, requires_grad=True)
+    up_n, up_o = torch.randn(B, H * W, C, device=DEV), torch.randn(B, C, H, W, device=DEV)
+    assert hip_engine.attention_block_supported(ln, x)
+
+    def native():
+        normed = hip_engine.ln_tokens(ln, x)
+        out = hip_engine.tokens_residual_nchw(tok, x)
+        grads = torch.autograd.grad([normed, out], [x, ln.weight, ln.bias, tok], [up_n, up_o])
+        return (normed.detach(), out.detach()) + grads
+
+    got = native()
+    ln64 = torch.nn.LayerNorm(C).double()
+    ln64.load_state_dict({k: v.double().cpu() for k, v in ln.state_dict().items()})
+    x64, tok64 = x.detach().double().cpu().requires_grad_(True), tok.detach().double().cpu().requires_grad_(True)
+    tokens = x64.reshape(-1, C, H * W).permute(0, 2, 1)
+    normed64 = ln64(tokens)
+    out64 = (tok64 + tokens).permute(0, 2, 1).reshape(-1, C, H, W)
+    want = (normed64.detach(), out64.detach()) + torch.autograd.grad([normed64, out64], [x64, ln64.weight, ln64.bias, tok64],
+                                                                      [up_n.double().cpu(), up_o.double().cpu()])
+    for a, b, what in zip(got, want, ("normed", "out", "dx", "dgamma", "dbeta", "dtokens")):
+        close(a.cpu(), b, 1e-5, what)
+    for a, b in zip(got, native()):
+        assert torch.equal(a, b)
+
+
 def native_call_counters(monkeypatch):
     names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
              "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
-             "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad")
+             "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
+             "danra_tokens_to_nchw_add")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
@@ -502,7 +540,9 @@ EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bw
                          "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
                          "danra_conv3x3_train_wgrad": 17,
                          # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
-                         "danra_pointwise_train_fwd": 8, "danra_pointwise_train_dgrad": 8, "danra_pointwise_train_wgrad": 8}
+                         "danra_pointwise_train_fwd": 8, "danra_pointwise_train_dgrad": 8, "danra_pointwise_train_wgrad": 8,
+                         # entry and exit of the nine attention blocks
+                         "danra_ln_tokens_fwd": 9, "danra_ln_tokens_bwd": 9, "danra_tokens_to_nchw_add": 9}
 
 
 def test_train_mode_network_uses_the_native_kernels(monkeypatch):
