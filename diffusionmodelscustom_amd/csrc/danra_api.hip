@@ -1339,9 +1339,10 @@ int danra_pointwise_train_fwd(int kind, const float* x, const float* w, const fl
 }
 
 int danra_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W,
-                                void* stream) {
+                                void* workspace, void* stream) {
     RC_TRY(pointwise_train_check(dy, w, dx, kind, B, Cin, Cout, H, W));
-    HIP_TRY(launch_pointwise_train_dgrad(kind, dy, w, dx, B, Cin, Cout, H, W, (hipStream_t)stream));
+    if (!workspace) return fail(DANRA_EINVAL, "null workspace");
+    HIP_TRY(launch_pointwise_train_dgrad(kind, dy, w, dx, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
     return DANRA_OK;
 }
 

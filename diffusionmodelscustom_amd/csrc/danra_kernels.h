@@ -259,7 +259,7 @@ size_t pointwise_train_workspace_floats(int kind, int B, int Cin, int Cout, int 
 hipError_t launch_pointwise_train_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                                       int Cout, int H, int W, hipStream_t stream);
 hipError_t launch_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H,
-                                        int W, hipStream_t stream);
+                                        int W, float* workspace, hipStream_t stream);
 hipError_t launch_pointwise_train_wgrad(int kind, const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H,
                                         int W, float* workspace, hipStream_t stream);
 __global__ void k_sum_slices(const float* __restrict__ part, float* __restrict__ out, int count4, int slices);

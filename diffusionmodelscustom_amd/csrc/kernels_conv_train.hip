@@ -438,7 +438,7 @@ __device__ __forceinline__ size_t pw_addr(const PwTensor& t, int b, int v, int y
     return (((size_t)b * t.C + v) * t.H + t.stride * y) * t.W + t.stride * x;
 }
 
-constexpr int PW_KC = 32;  // (virtual) reduction channels per chunk
+constexpr int PW_KC = 64;  // (virtual) reduction channels per chunk
 constexpr int PW_LDA = PW_KC + 1;
 
 }  // namespace
@@ -448,7 +448,8 @@ constexpr int PW_LDA = PW_KC + 1;
 // channels; waves as in k_conv3x3_train: pixel half x half of a chunk's 16 two-deep steps.
 __global__ __launch_bounds__(256) void k_pw_train(const float* __restrict__ in, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ out, const PwTensor ti,
-                                                  const PwTensor to, int B, int Hc, int Wc, int Cv, int Nv, int sn, int sc) {
+                                                  const PwTensor to, int B, int Hc, int Wc, int Cv, int Nv, int sn, int sc,
+                                                  int chunks_per_split) {
     __shared__ float bt[PW_KC * 64];       // [c][pixel]
     __shared__ float at[32 * PW_LDA];      // [n][c]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -466,37 +467,41 @@ __global__ __launch_bounds__(256) void k_pw_train(const float* __restrict__ in, 
     };
     int sb, sy, sx;
     decode(p0 + (tid & 63), sb, sy, sx);
-    const int c_first = tid >> 6;  // channels c_first + 4 i, i = 0..7
-    // A tile: 1024 values, 4 per thread; coalesced along whichever index has stride 1
-    int asrc[4], adst[4];
+    constexpr int NB = PW_KC * 64 / 256, NA = 32 * PW_KC / 256;  // B and A values a thread stages per chunk
+    const int c_first = tid >> 6;  // channels c_first + 4 i, i = 0..NB-1
+    // A tile: coalesced along whichever index has stride 1
+    int asrc[NA], adst[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int e = tid + 256 * i;
         const int n = sc == 1 ? e / PW_KC : e % 32, c = sc == 1 ? e % PW_KC : e / 32;
         asrc[i] = (n0 + n) * sn + c * sc;
         adst[i] = n * PW_LDA + c;
     }
-    float breg[8], areg[4];
+    float breg[NB], areg[NA];
     auto load_chunk = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) breg[i] = in[pw_addr(ti, sb, c0 + c_first + 4 * i, sy, sx)];
+        for (int i = 0; i < NB; ++i) breg[i] = in[pw_addr(ti, sb, c0 + c_first + 4 * i, sy, sx)];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) areg[i] = w[asrc[i] + c0 * sc];
+        for (int i = 0; i < NA; ++i) areg[i] = w[asrc[i] + c0 * sc];
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* arow = at + l32 * PW_LDA + kk;
     const float* bcol = bt + kk * 64 + pt * 32 + l32;
-    load_chunk(0);
-    for (int c0 = 0; c0 < Cv; c0 += PW_KC) {
+    // blockIdx.z: a range of chunks, result to slab z (plain output tensors only: the host sums the slabs)
+    const int c_lo = blockIdx.z * chunks_per_split * PW_KC, c_hi = min(Cv, c_lo + chunks_per_split * PW_KC);
+    out += (size_t)blockIdx.z * ((size_t)M * Nv);
+    load_chunk(min(c_lo, Cv - PW_KC));
+    for (int c0 = c_lo; c0 < c_hi; c0 += PW_KC) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bt[(c_first + 4 * i) * 64 + (tid & 63)] = breg[i];
+        for (int i = 0; i < NB; ++i) bt[(c_first + 4 * i) * 64 + (tid & 63)] = breg[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) at[adst[i]] = areg[i];
+        for (int i = 0; i < NA; ++i) at[adst[i]] = areg[i];
         __syncthreads();
-        if (c0 + PW_KC < Cv) load_chunk(c0 + PW_KC);
+        if (c0 + PW_KC < c_hi) load_chunk(c0 + PW_KC);
 #pragma unroll
         for (int s = 0; s < PW_KC / 4; ++s) {
             const int pair = kh * (PW_KC / 4) + s;
@@ -550,22 +555,25 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_train(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int px = tid & 63, cq = tid >> 6;
-    for (int q = q_begin; q < q_end; ++q) {
-        const int p = q * 64 + px;
-        const bool ok = p < M;
-        const int pc = min(p, M - 1);
+    float yv[16], xv[8];
+    auto load_chunk = [&](int q) {  // (a pixel past the end re-reads the last one; zeroed when stored)
+        const int pc = min(q * 64 + px, M - 1);
         const int b = pc / hw, r = pc - b * hw, y = r / Wc, x = r - y * Wc;
-        float yv[16], xv[8];
 #pragma unroll
         for (int i = 0; i < 16; ++i) yv[i] = Y[pw_addr(ty, b, n0 + cq + 4 * i, y, x)];
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[i] = X[pw_addr(tx, b, c0 + cq + 4 * i, y, x)];
+    };
+    if (q_begin < q_end) load_chunk(q_begin);
+    for (int q = q_begin; q < q_end; ++q) {
+        const bool ok = q * 64 + px < M;
         __syncthreads();  // the previous chunk has been multiplied
 #pragma unroll
         for (int i = 0; i < 16; ++i) yt[(cq + 4 * i) * LD + px] = ok ? yv[i] : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) xt[(cq + 4 * i) * LD + px] = ok ? xv[i] : 0.f;
         __syncthreads();
+        if (q + 1 < q_end) load_chunk(q + 1);
         const float* arow = yt + (nt * 32 + l32) * LD + kk;
         const float* bcol = xt + l32 * LD + kk;
 #pragma unroll
@@ -603,7 +611,7 @@ struct PwPlan {
 bool pw_plan(int kind, int B, int Cin, int Cout, int H, int W, PwPlan& p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
     if (kind == 0) {
-        if ((H & 1) || (W & 1) || Cin % 32 || Cout % 64) return false;
+        if ((H & 1) || (W & 1) || Cin % 64 || Cout % 64) return false;
         p.Hc = H / 2; p.Wc = W / 2;
         p.x = PwTensor{Cin, H, W, 0, 2};
         p.y = PwTensor{Cout, H / 2, W / 2, 0, 1};
@@ -618,7 +626,7 @@ bool pw_plan(int kind, int B, int Cin, int Cout, int H, int W, PwPlan& p) {
         return false;
     }
     const long long big = (long long)B * (p.xv > p.yv ? p.xv : p.yv) * p.Hc * p.Wc;
-    return big < (1LL << 31);
+    return big < (1LL << 31) && (long long)p.xv * p.yv < (1LL << 31);
 }
 
 void pw_wgrad_split(const PwPlan& p, int B, int Nv, int Cv, int& slices, int& cps) {
@@ -626,12 +634,14 @@ void pw_wgrad_split(const PwPlan& p, int B, int Nv, int Cv, int& slices, int& cp
     const long tiles = (long)(Nv / 64) * (Cv / 32);
     long s = tiles >= 128 ? 1 : (256 + tiles - 1) / tiles;
     if (s > n_chunks) s = n_chunks;
-    if (s > 64) s = 64;
+    if (s > 128) s = 128;
     cps = (int)((n_chunks + s - 1) / s);
     slices = (n_chunks + cps - 1) / cps;
 }
 
 }  // namespace
+
+static void pw_dgrad_split(const PwPlan& p, int kind, int B, int& ks, int& cps);
 
 bool pointwise_train_supported(int kind, int B, int Cin, int Cout, int H, int W) {
     PwPlan p;
@@ -643,9 +653,12 @@ size_t pointwise_train_workspace_floats(int kind, int B, int Cin, int Cout, int 
     if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return 0;
     // weight gradient: rows = the operand with at least 64 (virtual) channels per tile row (see launch_pointwise_wgrad_train)
     const int Nv = kind == 0 ? p.yv : p.xv, Cv = kind == 0 ? p.xv : p.yv;
-    int sl, cps;
+    int sl, cps, ks;
     pw_wgrad_split(p, B, Nv, Cv, sl, cps);
-    return sl > 1 ? (size_t)sl * Nv * Cv : 4;
+    size_t need = sl > 1 ? (size_t)sl * Nv * Cv : 4;
+    pw_dgrad_split(p, kind, B, ks, cps);
+    if (ks > 1) need = std::max(need, (size_t)ks * B * p.Hc * p.Wc * p.xv);
+    return need;
 }
 
 hipError_t launch_pointwise_train_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
@@ -656,21 +669,37 @@ hipError_t launch_pointwise_train_fwd(int kind, const float* x, const float* w, 
     const dim3 grid((M + 63) / 64, p.yv / 32);
     // kind 0: A[n = co][c = ci] = w[co * Cin + ci]; kind 1: A[n = (co, d)][c = ci] = w[ci * 4 Cout + n]
     hipLaunchKernelGGL(k_pw_train, grid, dim3(256), 0, stream, x, w, bias, y, p.x, p.y, B, p.Hc, p.Wc, p.xv, p.yv,
-                       kind == 0 ? Cin : 1, kind == 0 ? 1 : 4 * Cout);
+                       kind == 0 ? Cin : 1, kind == 0 ? 1 : 4 * Cout, p.xv / PW_KC);
     return hipGetLastError();
 }
 
+// the data gradient of a transposed convolution reduces over 4 Cout virtual channels (up to 2048) into a plain tensor: on the
+// small maps that reduction is split over workgroups (slabs in `workspace`, added in slab order)
+static void pw_dgrad_split(const PwPlan& p, int kind, int B, int& ks, int& cps) {
+    const int nchunks = p.yv / PW_KC;
+    const long base = (long)((B * p.Hc * p.Wc + 63) / 64) * (p.xv / 32);
+    ks = 1;
+    if (kind == 1)
+        while (base * ks < 256 && nchunks / (ks * 2) >= 2 && ks < 16) ks *= 2;
+    cps = (nchunks + ks - 1) / ks;
+    ks = (nchunks + cps - 1) / cps;
+}
+
 hipError_t launch_pointwise_train_dgrad(int kind, const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H,
-                                        int W, hipStream_t stream) {
+                                        int W, float* workspace, hipStream_t stream) {
     PwPlan p;
     if (!pw_plan(kind, B, Cin, Cout, H, W, p)) return hipErrorInvalidValue;
     const int M = B * p.Hc * p.Wc;
     // (kind 0: only every second pixel of every second row receives a gradient; the kernel writes the zeros between them)
-    const dim3 grid((M + 63) / 64, p.xv / 32);
+    int ks, cps;
+    pw_dgrad_split(p, kind, B, ks, cps);
+    const dim3 grid((M + 63) / 64, p.xv / 32, ks);
     // kind 0: A[n = ci][c = co] = w[co * Cin + ci]; kind 1: A[n = ci][c = (co, d)] = w[ci * 4 Cout + c]
-    hipLaunchKernelGGL(k_pw_train, grid, dim3(256), 0, stream, dy, w, (const float*)nullptr, dx, p.y, p.x, B, p.Hc, p.Wc, p.yv,
-                       p.xv, kind == 0 ? 1 : 4 * Cout, kind == 0 ? Cin : 1);
-    return hipGetLastError();
+    hipLaunchKernelGGL(k_pw_train, grid, dim3(256), 0, stream, dy, w, (const float*)nullptr, ks > 1 ? workspace : dx, p.y, p.x, B,
+                       p.Hc, p.Wc, p.yv, p.xv, kind == 0 ? 1 : 4 * Cout, kind == 0 ? Cin : 1, cps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return sum_slabs(workspace, dx, (size_t)M * p.xv, ks, stream);
 }
 
 hipError_t launch_pointwise_train_wgrad(int kind, const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H,

@@ -84,7 +84,7 @@ _SIGNATURES = {
     "danra_pointwise_train_supported": (ctypes.c_int, [ctypes.c_int] * 6),
     "danra_pointwise_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "danra_pointwise_train_fwd": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P] + [ctypes.c_int] * 5 + [_P]),
-    "danra_pointwise_train_dgrad": (ctypes.c_int, [ctypes.c_int, _P, _P, _P] + [ctypes.c_int] * 5 + [_P]),
+    "danra_pointwise_train_dgrad": (ctypes.c_int, [ctypes.c_int, _P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_pointwise_train_wgrad": (ctypes.c_int, [ctypes.c_int, _P, _P, _P] + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_conv3x3_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "danra_conv3x3_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
@@ -638,14 +638,14 @@ class _PointwiseTrain(torch.autograd.Function):
         dy = _f32(dy, "dy")
         dx = dw = db = None
         with torch.cuda.device(x.device):
+            ws = torch.empty(max(lib.danra_pointwise_train_workspace(kind, B, Cin, Cout, H, W) // 4, 1), device=x.device,
+                             dtype=torch.float32)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W,
+                _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W, _ptr(ws),
                                                             _stream()), "danra_pointwise_train_dgrad")
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
-                ws = torch.empty(max(lib.danra_pointwise_train_workspace(kind, B, Cin, Cout, H, W) // 4, 1), device=x.device,
-                                 dtype=torch.float32)
                 _check(lib, lib.danra_pointwise_train_wgrad(kind, _ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
                                                             _stream()), "danra_pointwise_train_wgrad")
             if ctx.has_bias and ctx.needs_input_grad[2]:

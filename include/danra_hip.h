@@ -254,11 +254,11 @@ int danra_tokens_to_nchw_add(const float* tokens_dev, const float* add_dev, floa
  * gradient and weight gradient, on contiguous NCHW fp32 tensors with torch's weight layouts; H, W = the layer's INPUT map:
  *   kind DANRA_PW_CONV1X1_S2 (0): nn.Conv2d(Cin, Cout, 1, stride 2, bias=False), the shortcut of a BasicBlock that halves
  *     the map (torchvision's downsample[0], built by modules_DANRA_conditional.py:154); w [Cout][Cin][1][1];
- *     y [B][Cout][H/2][W/2].  Supported: H, W even, Cin a multiple of 32, Cout of 64.
+ *     y [B][Cout][H/2][W/2].  Supported: H, W even, Cin and Cout multiples of 64.
  *   kind DANRA_PW_CONVT2X2 (1): nn.ConvTranspose2d(Cin, Cout, 2, stride 2), the up-sampling of a decoder block
  *     (modules_DANRA_conditional.py:408-411); w [Cin][Cout][2][2]; y [B][Cout][2H][2W]; `bias_dev` ([Cout] or NULL) is added
  *     by the forward call.  Supported: Cin a multiple of 64, Cout of 16.
- * The weight gradient takes danra_pointwise_train_workspace(...) bytes of the caller's device memory (slabs added in a fixed
+ * The two gradients take danra_pointwise_train_workspace(...) bytes of the caller's device memory (slabs added in a fixed
  * order); nothing is allocated. */
 #define DANRA_PW_CONV1X1_S2 0
 #define DANRA_PW_CONVT2X2 1
@@ -267,7 +267,7 @@ size_t danra_pointwise_train_workspace(int kind, int B, int Cin, int Cout, int H
 int danra_pointwise_train_fwd(int kind, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B,
                               int Cin, int Cout, int H, int W, void* stream);
 int danra_pointwise_train_dgrad(int kind, const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int Cout,
-                                int H, int W, void* stream);
+                                int H, int W, void* workspace_dev, void* stream);
 int danra_pointwise_train_wgrad(int kind, const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout,
                                 int H, int W, void* workspace_dev, void* stream);
 

@@ -145,7 +145,8 @@ def test_pointwise_kernels_match_float64(kind, B, Cin, Cout, H, W):
         dx, dw = torch.full_like(xg, float("nan")), torch.empty_like(wg)
         ws = torch.empty(max(lib.danra_pointwise_train_workspace(kind, B, Cin, Cout, H, W) // 4, 1), device=DEV)
         _check(lib, lib.danra_pointwise_train_fwd(kind, _ptr(xg), _ptr(wg), _ptr(bg), _ptr(y), B, Cin, Cout, H, W, _stream()), "fwd")
-        _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dyg), _ptr(wg), _ptr(dx), B, Cin, Cout, H, W, _stream()), "dgrad")
+        _check(lib, lib.danra_pointwise_train_dgrad(kind, _ptr(dyg), _ptr(wg), _ptr(dx), B, Cin, Cout, H, W, _ptr(ws), _stream()),
+               "dgrad")
         _check(lib, lib.danra_pointwise_train_wgrad(kind, _ptr(xg), _ptr(dyg), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws), _stream()),
                "wgrad")
         torch.cuda.synchronize()
