@@ -1196,6 +1196,30 @@ int danra_batchnorm_train_bwd(const float* x, const float* dy, const float* y, c
     return DANRA_OK;
 }
 
+int danra_batchnorm_train_add_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, int B, int C,
+                                       int HW, float eps, float momentum, void* stream) {
+    if (!x || !res || !gamma || !beta || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return fail(DANRA_EINVAL, "running_mean and running_var go together");
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * HW < 2 || (long long)B * C * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, at least two values per channel, "
+                    "fewer than 2^31 elements", B, C, HW);
+    HIP_TRY(launch_bn_train_fwd(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, B, C, HW, eps, momentum, 1,
+                                (hipStream_t)stream, res));
+    return DANRA_OK;
+}
+
+int danra_batchnorm_train_add_relu_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+                                       const float* save_mean, const float* save_rstd, float* dx, float* dres, float* dgamma,
+                                       float* dbeta, int B, int C, int HW, void* stream) {
+    if (!x || !dy || !y || !gamma || !save_mean || !save_rstd || !dx || !dres || !dgamma || !dbeta)
+        return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * C * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", B, C, HW);
+    HIP_TRY(launch_bn_train_bwd(x, dy, y, gamma, save_mean, save_rstd, dx, dgamma, dbeta, B, C, HW, 1, (hipStream_t)stream, dres));
+    return DANRA_OK;
+}
+
 int danra_instancenorm_fwd(const float* x, float* y, float* save_mean, float* save_rstd, int planes, int HW, float eps,
                            void* stream) {
     if (!x || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");

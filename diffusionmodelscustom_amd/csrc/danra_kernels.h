@@ -216,11 +216,11 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H
 // [C] feed the backward pass; running_mean / running_var (may be null) are updated with `momentum` (unbiased variance).
 hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                                float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
-                               float momentum, int relu, hipStream_t stream);
+                               float momentum, int relu, hipStream_t stream, const float* res = nullptr);
 // y is the forward's output (read only with relu, for the mask)
 hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
                                const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
-                               hipStream_t stream);
+                               hipStream_t stream, float* dres = nullptr);
 
 // InstanceNorm2d(affine=False) on NCHW fp32, `planes` = B*C planes of HW values (HW a multiple of 4), with its backward
 hipError_t launch_in_train_fwd(const float* x, float* y, float* save_mean, float* save_rstd, int planes, int HW, float eps,

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float* __restrict__ 
                                                       const float* __restrict__ beta, float* __restrict__ y,
                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                      int B, int C, int HW, float eps, float momentum, int relu) {
+                                                      int B, int C, int HW, float eps, float momentum, int relu,
+                                                      const float* __restrict__ res) {
     __shared__ float red[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int hw4 = HW / 4;            // HW is a multiple of 4 (checked by the launcher)
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float* __restrict__ 
         const size_t o = item(i);
         const float4 v = *reinterpret_cast<const float4*>(x + o);
         float4 r = make_float4((v.x - mean) * g + sh, (v.y - mean) * g + sh, (v.z - mean) * g + sh, (v.w - mean) * g + sh);
+        if (res) {  // the block's shortcut, added in front of the ReLU
+            const float4 a = *reinterpret_cast<const float4*>(res + o);
+            r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+        }
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
         *reinterpret_cast<float4*>(y + o) = r;
     }
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void k_bn_train_bwd(const float* __restrict__ 
                                                       const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_rstd, float* __restrict__ dx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
-                                                      int HW, int relu) {
+                                                      int HW, int relu, float* __restrict__ dres) {
     __shared__ float red[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int hw4 = HW / 4;
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void k_bn_train_bwd(const float* __restrict__ 
         r.z = k * (g.z - mb - (v.z - mean) * rstd * mg);
         r.w = k * (g.w - mb - (v.w - mean) * rstd * mg);
         *reinterpret_cast<float4*>(dx + o) = r;
+        if (dres) *reinterpret_cast<float4*>(dres + o) = g;  // the shortcut's gradient: dy behind the ReLU mask
     }
 }
 
@@ -209,19 +215,19 @@ hipError_t launch_in_train_bwd(const float* x, const float* dy, const float* sav
 
 hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                                float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
-                               float momentum, int relu, hipStream_t stream) {
+                               float momentum, int relu, hipStream_t stream, const float* res) {
     if (HW % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bn_train_fwd, dim3(C), dim3(256), 0, stream, x, gamma, beta, y, save_mean, save_rstd, running_mean,
-                       running_var, B, C, HW, eps, momentum, relu);
+                       running_var, B, C, HW, eps, momentum, relu, res);
     return hipGetLastError();
 }
 
 hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
                                const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
-                               hipStream_t stream) {
+                               hipStream_t stream, float* dres) {
     if (HW % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bn_train_bwd, dim3(C), dim3(256), 0, stream, x, dy, y, gamma, save_mean, save_rstd, dx, dgamma, dbeta,
-                       B, C, HW, relu);
+                       B, C, HW, relu, dres);
     return hipGetLastError();
 }
 

@@ -69,6 +69,8 @@ _SIGNATURES = {
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_int, _P]),
     "danra_batchnorm_train_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, _P]),
+    "danra_batchnorm_train_add_relu_fwd": (ctypes.c_int, [_P] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _P]),
+    "danra_batchnorm_train_add_relu_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int] * 3 + [_P]),
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -410,6 +412,53 @@ class _BatchNormTrain(torch.autograd.Function):
                                                       _ptr(save_rstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, H * W,
                                                       int(ctx.relu), _stream()), "danra_batchnorm_train_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _BatchNormAddReluTrain(torch.autograd.Function):
+    """relu(bn(x) + res) for a train-mode nn.BatchNorm2d - the tail of a BasicBlock - as one kernel in either direction
+    (danra_batchnorm_train_add_relu_fwd / _bwd) on contiguous NCHW fp32 CUDA tensors."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum):
+        lib = load_library()
+        x, res = x.contiguous(), res.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        save_rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_batchnorm_train_add_relu_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y),
+                                                               _ptr(save_mean), _ptr(save_rstd), _ptr(running_mean),
+                                                               _ptr(running_var), B, C, H * W, ctypes.c_float(eps),
+                                                               ctypes.c_float(momentum), _stream()),
+                   "danra_batchnorm_train_add_relu_fwd")
+        ctx.save_for_backward(x, y, gamma, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, y, gamma, save_mean, save_rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _f32(dy, "dy")
+        dx, dres = torch.empty_like(x), torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_batchnorm_train_add_relu_bwd(_ptr(x), _ptr(dy), _ptr(y), _ptr(gamma), _ptr(save_mean),
+                                                               _ptr(save_rstd), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta),
+                                                               B, C, H * W, _stream()), "danra_batchnorm_train_add_relu_bwd")
+        return dx, dres, dgamma, dbeta, None, None, None, None
+
+
+def batchnorm_add_relu_train(bn, x, res):
+    """relu(bn(x) + res) for a train-mode nn.BatchNorm2d through the native kernel (see batchnorm_train_supported; `res` has
+    x's shape)."""
+    with torch.no_grad():
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormAddReluTrain.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                                        float(bn.momentum))
 
 
 def batchnorm_train_supported(bn, x):

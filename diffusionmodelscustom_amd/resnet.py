@@ -54,8 +54,12 @@ class BasicBlock(nn.Module):
         else:
             shortcut = self.downsample(x)
         y = norm_relu(self.bn1, self.relu, conv2d(self.conv1, x))
-        y = norm_relu(self.bn2, None, conv2d(self.conv2, y))
-        return self.relu(y + shortcut)
+        z = conv2d(self.conv2, y)
+        if z.is_cuda and type(self.bn2) is nn.BatchNorm2d and self.bn2.training and shortcut.shape == z.shape:
+            from . import hip_engine
+            if hip_engine.batchnorm_train_supported(self.bn2, z) and hip_engine._native_dtype(shortcut):
+                return hip_engine.batchnorm_add_relu_train(self.bn2, z, shortcut)  # bn2, + shortcut, ReLU: one kernel
+        return self.relu(norm_relu(self.bn2, None, z) + shortcut)
 
 
 class ResNet(nn.Module):

@@ -188,6 +188,16 @@ int danra_batchnorm_train_bwd(const float* x_dev, const float* dy_dev, const flo
                               const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dgamma_dev,
                               float* dbeta_dev, int B, int C, int HW, int relu, void* stream);
 
+/* The tail of a torchvision BasicBlock in train mode, relu(bn2(z) + shortcut) (modules_DANRA_conditional.py:154,276-303), as
+ * one kernel in either direction: y = relu(BatchNorm_train(x) + res); backward: dres = dy where y > 0 (else 0), dx / dgamma /
+ * dbeta as danra_batchnorm_train_bwd for that masked gradient.  Same shapes and restrictions as danra_batchnorm_train_fwd. */
+int danra_batchnorm_train_add_relu_fwd(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
+                                       float* y_dev, float* save_mean_dev, float* save_rstd_dev, float* running_mean_dev,
+                                       float* running_var_dev, int B, int C, int HW, float eps, float momentum, void* stream);
+int danra_batchnorm_train_add_relu_bwd(const float* x_dev, const float* dy_dev, const float* y_dev, const float* gamma_dev,
+                                       const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dres_dev,
+                                       float* dgamma_dev, float* dbeta_dev, int B, int C, int HW, void* stream);
+
 /* nn.InstanceNorm2d(affine=False) as the decoder blocks use it (modules_DANRA_conditional.py:412,419) on NCHW fp32 with
  * its autograd backward, for the training step: `planes` = B*C planes of HW contiguous values each (HW a multiple of 4);
  * y = (x - mean) / sqrt(var_biased + eps) per plane; save_mean / save_rstd: [planes], kept for the backward pass

@@ -422,6 +422,34 @@ def test_batchnorm_train_kernels_match_torch(shape, relu):
     assert int(gpu.num_batches_tracked) == int(ref.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (3, 128, 8, 8), (5, 512, 2, 2)])
+def test_batchnorm_add_relu_kernels_match_torch(shape):
+    """danra_batchnorm_train_add_relu_fwd / _bwd - the tail of a BasicBlock, relu(bn2(z) + shortcut) - against the torch
+    composition in float64 on the CPU: output, running statistics, gradients of both inputs and of the norm's parameters."""
+    torch.manual_seed(22)
+    bn = torch.nn.BatchNorm2d(shape[1])
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x, res, dy = torch.randn(shape) * 2 + 0.7, torch.randn(shape), torch.randn(shape)
+    ref = copy.deepcopy(bn).double().train()
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    yr = torch.relu(ref(xr) + rr)
+    yr.backward(dy.double())
+    gpu = copy.deepcopy(bn).to(DEV).train()
+    xg, rg = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+    yg = hip_engine.batchnorm_add_relu_train(gpu, xg, rg)
+    yg.backward(dy.to(DEV))
+    close(yg.detach().cpu(), yr.detach(), 1e-5, "output")
+    close(xg.grad.cpu(), xr.grad, 1e-5, "input gradient")
+    close(rg.grad.cpu(), rr.grad, 1e-5, "shortcut gradient")
+    close(gpu.weight.grad.cpu(), ref.weight.grad, 1e-5, "weight gradient")
+    close(gpu.bias.grad.cpu(), ref.bias.grad, 1e-5, "bias gradient")
+    close(gpu.running_mean.cpu(), ref.running_mean, 1e-6, "running_mean")
+    close(gpu.running_var.cpu(), ref.running_var, 1e-6, "running_var")
+    assert int(gpu.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("M,N", [(32768, 192), (8192, 64), (4096 + 6, 128), (131072, 192), (70, 64), (1, 192)])
 def test_linear_weight_gradient_kernel_against_float64(M, N):
     """danra_linear_wgrad (dW = dy^T x, db = column sums of dy over M token rows) against a float64 evaluation: the
@@ -524,7 +552,8 @@ def test_attention_block_entry_and_exit_match_float64(B, C, H, W):
 
 def native_call_counters(monkeypatch):
     names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
-             "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
+             "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd",
+             "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd", "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
              "danra_tokens_to_nchw_add")
@@ -532,11 +561,12 @@ def native_call_counters(monkeypatch):
 
 
 # the conditional network: 4 attention blocks at 64 channels (core forward and backward, and the weight gradients of their
-# two projections); bn1 + 8 blocks x 2 + 3 shortcut norms; 4 decoder blocks x 2 InstanceNorms + the final block's first
+# two projections); bn1 + 8 blocks x 2 + 3 shortcut norms, the second norm of every block fused with the shortcut add and the ReLU; 4 decoder blocks x 2 InstanceNorms + the final block's first
 # (its second is an Identity); the 3x3 stride-1 convolutions: 4 + 3 + 3 + 3 in the BasicBlocks (the first convolution of
 # layers 2-4 has stride 2) and the four decoder blocks' (the final block's has one output channel), each in three directions
-EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 20,
-                         "danra_batchnorm_train_bwd": 20, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
+EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 12,
+                         "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
+                         "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
                          "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
                          "danra_conv3x3_train_wgrad": 17,
                          # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
