@@ -66,19 +66,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // so a staging thread writes its four columns as one 16-byte store and the fragment reads of a wave are 1 KB in a line.
 static constexpr int KHROW = 32;  // halves per key row of the fp16 K tile
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH>
+// KT64: 64-key sub-tiles per staged tile (one barrier per 64 * KT64 keys; 2 measured equal to 1 within the run-to-run
+// spread, in tune_flash and in the network, so the library uses 1)
+template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH, int KT64 = 1>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
                                                     float scale_log2e) {
     // fp32 tiles only in the all-fp32 form; the fp32 fallback of the fp16 forms (rare) reads global memory instead
     constexpr bool F32_TILES = !(PVH && QKH);
-    __shared__ __attribute__((aligned(16))) float Ks[F32_TILES ? 2 : 1][F32_TILES ? KVT * KROW : 4];
-    __shared__ __attribute__((aligned(16))) float Vs[F32_TILES ? 2 : 1][F32_TILES ? KVT * KROW : 4];
+    __shared__ __attribute__((aligned(16))) float Ks[F32_TILES ? 2 : 1][F32_TILES ? KT64 * KVT * KROW : 4];
+    __shared__ __attribute__((aligned(16))) float Vs[F32_TILES ? 2 : 1][F32_TILES ? KT64 * KVT * KROW : 4];
     // fp16 halves of the V tile in the A-operand order of the 32-deep product: [buffer][hi, lo][32-key half]
     // [d][g][slot], slot 4j + r <-> key 16j + 4g + r of the half (the order in which a lane holds its 8 scores)
-    __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2][PVH ? 16 * 4 * 8 : 8];
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[QKH ? 2 : 1][QKH ? KVT * KHROW : 8];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[PVH ? 2 : 1][2][2 * KT64][PVH ? 16 * 4 * 8 : 8];
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[QKH ? 2 : 1][QKH ? KT64 * KVT * KHROW : 8];
     // range flags, one per staging buffer: set (never cleared) by the threads that stage a tile into that buffer and read
     // at the top of the iteration that consumes it.  With a single flag a wave that runs ahead could raise it for tile
     // kt + 2 while a slower wave still decides about tile kt + 1, and which products that wave then used would depend on
@@ -173,17 +175,21 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int srow = tid >> 2, sc4 = (tid & 3) * 4;
     const int vd = lane >> 2, vg = lane & 3, vj = wave & 1, vhalf = wave >> 1;
     const int vkey = 32 * vhalf + 16 * vj + 4 * vg;  // first of this thread's four keys within a tile
-    float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
-    float4 vreg;
-    auto load_v = [&](int tile) {
-        if (PVH) {
-            const float* vp = Vb + (size_t)(tile * KVT + vkey) * 16 + vd;
-            vreg = make_float4(vp[0], vp[16], vp[32], vp[48]);
-        } else {
-            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * KVT + srow) * 16 + sc4);
+    constexpr int TK = KT64 * KVT;  // keys per staged tile
+    float4 kreg[KT64], vreg[KT64];
+    auto load_kv = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < KT64; ++u) {
+            kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(tile * TK + KVT * u + srow) * 16 + sc4);
+            if (PVH) {
+                const float* vp = Vb + (size_t)(tile * TK + KVT * u + vkey) * 16 + vd;
+                vreg[u] = make_float4(vp[0], vp[16], vp[32], vp[48]);
+            } else {
+                vreg[u] = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * TK + KVT * u + srow) * 16 + sc4);
+            }
         }
     };
-    load_v(0);
+    load_kv(0);
     // x = h + 2^-11 l: h = fp16(x) rounded towards zero, l = fp16(2^11 (x - h)) (the difference is exact in fp32);
     // five instructions per pair of values
     auto split_scaled = [&](float x0, float x1, unsigned& h, unsigned& l) {
@@ -195,29 +201,33 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto stage = [&](int buf) {
-        if (F32_TILES) {
-            *reinterpret_cast<float4*>(&Ks[buf][srow * KROW + sc4]) = kreg;
-            *reinterpret_cast<float4*>(&Vs[buf][srow * KROW + sc4]) = vreg;
-        }
-        if (QKH) {
-            unsigned h[2], l[2];
-            split_scaled(kreg.x, kreg.y, h[0], l[0]);
-            split_scaled(kreg.z, kreg.w, h[1], l[1]);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<u32x4*>(&Kh[buf][srow * KHROW + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
-            const float kmax = fmaxf(max3f(fabsf(kreg.x), fabsf(kreg.y), fabsf(kreg.z)), fabsf(kreg.w));
-            if (!(kmax < 32768.f)) vbig_s[buf] = 1;
-        }
-        if (PVH) {
-            unsigned h[2], l[2];
-            split_scaled(vreg.x, vreg.y, h[0], l[0]);
-            split_scaled(vreg.z, vreg.w, h[1], l[1]);
-            const int at = (vd * 4 + vg) * 8 + 4 * vj;
-            *reinterpret_cast<u32x2*>(&Vh[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
-            *reinterpret_cast<u32x2*>(&Vh[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
-            const float vmax = fmaxf(max3f(fabsf(vreg.x), fabsf(vreg.y), fabsf(vreg.z)), fabsf(vreg.w));
-            // (a wave stages 16 keys x 16 columns.)  Never cleared: the tiles from this one on are multiplied in fp32
-            if (!(vmax < 32768.f) || __all(vmax < 0.0009765625f)) vbig_s[buf] = 1;
+#pragma unroll
+        for (int u = 0; u < KT64; ++u) {
+            const float4 kr = kreg[u], vr = vreg[u];
+            if (F32_TILES) {
+                *reinterpret_cast<float4*>(&Ks[buf][(KVT * u + srow) * KROW + sc4]) = kr;
+                *reinterpret_cast<float4*>(&Vs[buf][(KVT * u + srow) * KROW + sc4]) = vr;
+            }
+            if (QKH) {
+                unsigned h[2], l[2];
+                split_scaled(kr.x, kr.y, h[0], l[0]);
+                split_scaled(kr.z, kr.w, h[1], l[1]);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<u32x4*>(&Kh[buf][(KVT * u + srow) * KHROW + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
+                const float kmax = fmaxf(max3f(fabsf(kr.x), fabsf(kr.y), fabsf(kr.z)), fabsf(kr.w));
+                if (!(kmax < 32768.f)) vbig_s[buf] = 1;
+            }
+            if (PVH) {
+                unsigned h[2], l[2];
+                split_scaled(vr.x, vr.y, h[0], l[0]);
+                split_scaled(vr.z, vr.w, h[1], l[1]);
+                const int at = (vd * 4 + vg) * 8 + 4 * vj;
+                *reinterpret_cast<u32x2*>(&Vh[buf][0][2 * u + vhalf][at]) = u32x2{h[0], h[1]};
+                *reinterpret_cast<u32x2*>(&Vh[buf][1][2 * u + vhalf][at]) = u32x2{l[0], l[1]};
+                const float vmax = fmaxf(max3f(fabsf(vr.x), fabsf(vr.y), fabsf(vr.z)), fabsf(vr.w));
+                // (a wave stages 16 keys x 16 columns.)  Never cleared: the tiles from this one on are multiplied in fp32
+                if (!(vmax < 32768.f) || __all(vmax < 0.0009765625f)) vbig_s[buf] = 1;
+            }
         }
     };
     if (PVH) {
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     stage(0);
     __syncthreads();
 
-    const int ntiles = L / KVT;
+    const int ntiles = L / TK;
     // fp32 products: always in the all-fp32 form; in the fp16 form from the first tile on for a wave whose own queries
     // leave the fp16 range, and for every wave from the first flagged K / V tile on
     bool vbig = PVH ? (__any(!q_bounded) != 0) : true;
@@ -236,8 +246,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         vbig = vbig || (__builtin_amdgcn_readfirstlane(vbig_s[buf]) != 0);  // from the first flagged tile on
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
-            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * KVT + srow) * 16 + sc4);
-            load_v(nxt);
+            load_kv(nxt);
         }
         // The 64-key tile is consumed in two halves of 32 keys (QK^T -> softmax -> PV each), which keeps
         // the live score registers at 8 per query tile.  `fast`: both products on the fp16 matrix cores; decided once
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         auto tile_body = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int hf = 0; hf < 2 * KT64; ++hf) {
             // ---- S^T tiles: s[t][j][r] = score(query q0+16t+lq, key 32hf + 16j + 4g + r) - reference
             f32x4 s[QT][2];
 #pragma unroll
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 }
                 const float4 kf = F32_TILES
                     ? *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g])
-                    : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * KVT + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
+                    : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * TK + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     f32x4 a = negm[t];
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 for (int r = 0; r < 4; ++r)
                     vf[r] = (ABL & 2) ? scale_log2e + (float)r
                           : F32_TILES ? Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq]
-                                      : Vb[(size_t)(kt * KVT + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
+                                      : Vb[(size_t)(kt * TK + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll

@@ -14,7 +14,7 @@ using namespace danra;
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 
-template <int ABL, bool PVH = true, bool QKH = PVH, int QT = 2>
+template <int ABL, bool PVH = true, bool QKH = PVH, int QT = 2, int KT64 = 1>
 static void run(const char* name, const float* q, const float* k, const float* v, float* o, int B, int L) {
     const int heads = 4;
     const float sc = 0.25f * 1.4426950408889634f;
@@ -22,10 +22,10 @@ static void run(const char* name, const float* q, const float* k, const float* v
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e0, 0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -48,6 +48,9 @@ int main(int argc, char** argv) {
     hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
     run<0>("full", q, k, v, o, B, L);
+    run<0, true, true, 2, 2>("full, 128 keys per barrier", q, k, v, o, B, L);
+    run<0>("full", q, k, v, o, B, L);
+    run<0, true, true, 2, 2>("full, 128 keys per barrier", q, k, v, o, B, L);
     run<0, true, true, 4>("full, 64 queries per wave", q, k, v, o, B, L);
     run<0, true, true, 1>("full, 16 queries per wave", q, k, v, o, B, L);
     {   // the fp16-halves product against the all-fp32 product on the same data
