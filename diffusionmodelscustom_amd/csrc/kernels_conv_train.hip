@@ -263,21 +263,21 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_train(const float* __rest
             int b, off;
             const bool ok = tile_pixel(g, tile, p, b, off);
             const float* src = dy + ((size_t)(ok ? b : 0) * Cout + co0 + cq) * hw + off;
+            float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = src[(size_t)(4 * i) * hw];  // unconditional: past the last image it re-reads image 0
-                dyt[(cq + 4 * i) * LDY + p] = ok ? v : 0.f;
-            }
+            for (int i = 0; i < 16; ++i) v[i] = src[(size_t)(4 * i) * hw];  // unconditional: past the last image it re-reads image 0
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dyt[(cq + 4 * i) * LDY + p] = ok ? v[i] : 0.f;
         }
         if (tid < g.WIN) {  // window: a thread keeps one window position and walks the 32 channels
             int b, y, xx;
             const bool ok = window_source(g, tile, tid, b, y, xx);
             const float* src = ok ? x + (((size_t)b * Cin + ci0) * g.H + y) * g.W + xx : x;
-#pragma unroll 8
-            for (int c = 0; c < 32; ++c) {
-                const float v = src[(size_t)c * hw];
-                win[c * WINP + tid] = ok ? v : 0.f;
-            }
+            float v[32];  // all 32 loads in flight before the first LDS write (an unroll by 8 paid the latency four times)
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = src[(size_t)c * hw];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) win[c * WINP + tid] = ok ? v[c] : 0.f;
         }
         __syncthreads();
         const float* arow = dyt + (cot * 32 + l32) * LDY + kk;
