@@ -1768,4 +1768,87 @@ int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void*
     return DANRA_OK;
 }
 
+// ---- elucidated (EDM) sampler steps
+static int edm_noise_args(const float* noise, int noise_mode) {
+    if (noise_mode != DANRA_NOISE_HOST && noise_mode != DANRA_NOISE_PHILOX) return fail(DANRA_EINVAL, "unknown noise mode");
+    if (noise_mode == DANRA_NOISE_HOST && !noise) return fail(DANRA_EINVAL, "noise_dev is null in DANRA_NOISE_HOST mode");
+    return DANRA_OK;
+}
+static int edm_image_args(int B, size_t per_image) {
+    if (B <= 0 || per_image == 0) return fail(DANRA_EINVAL, "B=%d per_image=%zu: both must be positive", B, per_image);
+    if (per_image >= ((size_t)1 << 32)) return fail(DANRA_EINVAL, "per_image=%zu: at most 2^32 - 1 values per image", per_image);
+    return DANRA_OK;
+}
+
+int danra_edm_perturb(const float* images, const float* noise, const float* inpaint, const unsigned char* mask,
+                      float* images_hat, float* net_in, int B, int C, int HW, float s_noise, float noise_scale, float c_in,
+                      int noise_mode, uint64_t seed, uint64_t offset, void* stream) {
+    if (!images || !images_hat || !net_in) return fail(DANRA_EINVAL, "null argument");
+    if (C <= 0 || HW <= 0) return fail(DANRA_EINVAL, "C=%d HW=%d: both must be positive", C, HW);
+    RC_TRY(edm_image_args(B, (size_t)C * HW));
+    RC_TRY(edm_noise_args(noise, noise_mode));
+    if ((inpaint == nullptr) != (mask == nullptr)) return fail(DANRA_EINVAL, "inpaint images and masks come together");
+    HIP_TRY(launch_edm_perturb(images, noise, inpaint, mask, images_hat, net_in, B, C, HW, s_noise, noise_scale, c_in,
+                               noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed, offset, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_precondition(const float* x, const float* net_out, float* model_out, size_t n, float c_skip, float c_out,
+                           int clamp, void* stream) {
+    if (!x || !net_out || !model_out) return fail(DANRA_EINVAL, "null argument");
+    if (n == 0) return fail(DANRA_EINVAL, "n must be positive");
+    HIP_TRY(launch_edm_precondition(x, net_out, model_out, n, c_skip, c_out, clamp ? 1 : 0, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_dynamic_threshold(const float* x, float* s_out, int B, size_t per_image, float percentile, void* stream) {
+    if (!x || !s_out) return fail(DANRA_EINVAL, "null argument");
+    RC_TRY(edm_image_args(B, per_image));
+    if (!(percentile >= 0.f && percentile <= 1.f)) return fail(DANRA_EINVAL, "percentile %g is outside [0, 1]", (double)percentile);
+    HIP_TRY(launch_edm_quantile_abs(x, s_out, B, per_image, percentile, 1.0f, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_euler(const float* images_hat, const float* net_out, float* model_out, const float* thresholds, float* d_out,
+                    float* images_next, float* net_in_next, int B, size_t per_image, float c_skip, float c_out, int clamp,
+                    float sigma_hat, float dt, float c_in_next, void* stream) {
+    if (!images_hat || !model_out || !images_next) return fail(DANRA_EINVAL, "null argument");
+    RC_TRY(edm_image_args(B, per_image));
+    if (sigma_hat == 0.f) return fail(DANRA_EINVAL, "sigma_hat is zero");
+    HIP_TRY(launch_edm_euler(images_hat, net_out, model_out, thresholds, d_out, images_next, net_in_next, B, per_image, c_skip,
+                             c_out, clamp ? 1 : 0, sigma_hat, dt, c_in_next, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_heun(const float* images_hat, const float* images_next, const float* net_out, float* model_out,
+                   const float* thresholds, const float* d, float* images_out, int B, size_t per_image, float c_skip,
+                   float c_out, int clamp, float sigma_next, float half_dt, void* stream) {
+    if (!images_hat || !images_next || !model_out || !d || !images_out) return fail(DANRA_EINVAL, "null argument");
+    RC_TRY(edm_image_args(B, per_image));
+    if (sigma_next == 0.f) return fail(DANRA_EINVAL, "sigma_next is zero: the last step has no second-order correction");
+    HIP_TRY(launch_edm_heun(images_hat, images_next, net_out, model_out, thresholds, d, images_out, B, per_image, c_skip,
+                            c_out, clamp ? 1 : 0, sigma_next, half_dt, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_renoise(float* images, const float* noise, size_t n, float scale, int noise_mode, uint64_t seed,
+                      uint64_t offset, void* stream) {
+    if (!images) return fail(DANRA_EINVAL, "null argument");
+    if (n == 0) return fail(DANRA_EINVAL, "n must be positive");
+    RC_TRY(edm_noise_args(noise, noise_mode));
+    HIP_TRY(launch_edm_renoise(images, noise, n, scale, noise_mode == DANRA_NOISE_PHILOX ? 1 : 0, seed, offset,
+                               (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_edm_finish(float* images, const float* inpaint, const unsigned char* mask, int B, int C, int HW, int unnormalize,
+                     void* stream) {
+    if (!images) return fail(DANRA_EINVAL, "null argument");
+    if (C <= 0 || HW <= 0) return fail(DANRA_EINVAL, "C=%d HW=%d: both must be positive", C, HW);
+    RC_TRY(edm_image_args(B, (size_t)C * HW));
+    if ((inpaint == nullptr) != (mask == nullptr)) return fail(DANRA_EINVAL, "inpaint images and masks come together");
+    HIP_TRY(launch_edm_finish(images, inpaint, mask, B, C, HW, unnormalize ? 1 : 0, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 }  // extern "C"

@@ -211,6 +211,26 @@ hipError_t launch_noise_image(const float* x, const int64_t* t, const float* alp
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, hipStream_t stream);
 
+// ---------------------------------------------------------------- elucidated (EDM) sampler steps, kernels_edm.hip
+// (NCHW fp32 images; `mask` is one byte per pixel and image, shared by the channels; `thr` one float per image)
+hipError_t launch_edm_perturb(const float* images, const float* noise, const float* inpaint, const unsigned char* mask,
+                              float* images_hat, float* net_in, int B, int C, int HW, float s_noise, float k, float c_in,
+                              int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
+hipError_t launch_edm_precondition(const float* x, const float* net, float* out, size_t n, float c_skip, float c_out,
+                                   int clamp, hipStream_t stream);
+hipError_t launch_edm_quantile_abs(const float* x, float* out, int B, size_t per_image, float q, float floor_value,
+                                   hipStream_t stream);
+hipError_t launch_edm_euler(const float* images_hat, const float* net, float* model_out, const float* thr, float* d_out,
+                            float* images_next, float* net_in_next, int B, size_t per_image, float c_skip, float c_out,
+                            int clamp, float sigma_hat, float dt, float c_in_next, hipStream_t stream);
+hipError_t launch_edm_heun(const float* images_hat, const float* images_next, const float* net, float* model_out,
+                           const float* thr, const float* d_in, float* images_out, int B, size_t per_image, float c_skip,
+                           float c_out, int clamp, float sigma_next, float half_dt, hipStream_t stream);
+hipError_t launch_edm_renoise(float* images, const float* noise, size_t n, float scale, int philox, uint64_t seed,
+                              uint64_t offset, hipStream_t stream);
+hipError_t launch_edm_finish(float* images, const float* inpaint, const unsigned char* mask, int B, int C, int HW,
+                             int unnormalize, hipStream_t stream);
+
 // ---------------------------------------------------------------- training step
 // BatchNorm2d in train mode on NCHW fp32 (HW a multiple of 4): batch statistics, optional fused ReLU; save_mean / save_rstd
 // [C] feed the backward pass; running_mean / running_var (may be null) are updated with `momentum` (unbiased variance).

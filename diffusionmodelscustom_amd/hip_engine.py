@@ -109,6 +109,17 @@ _SIGNATURES = {
     "danra_decoder_block": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_instance_norm": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_instance_norm_noalloc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_edm_perturb": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_uint64,
+                                                                                              ctypes.c_uint64, _P]),
+    "danra_edm_precondition": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int, _P]),
+    "danra_edm_dynamic_threshold": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, _P]),
+    "danra_edm_euler": (ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    "danra_edm_heun": (ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                                 ctypes.c_float, ctypes.c_float, _P]),
+    "danra_edm_renoise": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_float, ctypes.c_int, ctypes.c_uint64,
+                                         ctypes.c_uint64, _P]),
+    "danra_edm_finish": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 4 + [_P]),
     "danra_nchw_to_nhwc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_nhwc_to_nchw": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
 }
@@ -892,3 +903,109 @@ class UNetEngine:
                 if keep is not None:
                     keep.record_stream(torch.cuda.current_stream())
         return (x, trace) if trace_steps else x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The steps of the elucidated (EDM) sampler (CascadedDDPM/elucidated_imagen.py:393-545), thin wrappers of the C entries.
+# Images are contiguous CUDA float32 NCHW tensors; `mask` is a contiguous CUDA uint8 tensor [B, H, W] (or [B, 1, H, W]).
+def _u64(v):
+    return ctypes.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _edm_plain(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name} must be a contiguous CUDA float32 tensor")
+    return t
+
+
+def _edm_mask(mask, images):
+    if mask is None:
+        return None
+    B, HW = images.shape[0], images.shape[-1] * images.shape[-2]
+    if not (mask.is_cuda and mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == B * HW):
+        raise RuntimeError("mask must be a contiguous CUDA uint8 tensor with one value per image and pixel")
+    return mask
+
+
+def _edm_dims(images):
+    if images.dim() != 4:
+        raise RuntimeError("images must be [B, C, H, W]")
+    B, C, H, W = images.shape
+    return B, C, H * W
+
+
+def edm_perturb(images, images_hat, net_in, s_noise, noise_scale, c_in, noise=None, seed=0, offset=0, inpaint=None,
+                mask=None):
+    lib = load_library()
+    B, C, HW = _edm_dims(_edm_plain(images, "images"))
+    with torch.cuda.device(images.device):
+        _check(lib, lib.danra_edm_perturb(
+            _ptr(images), _ptr(_edm_plain(noise, "noise")), _ptr(_edm_plain(inpaint, "inpaint")),
+            _ptr(_edm_mask(mask, images)), _ptr(_edm_plain(images_hat, "images_hat")), _ptr(_edm_plain(net_in, "net_in")),
+            B, C, HW, s_noise, noise_scale, c_in, NOISE_PHILOX if noise is None else NOISE_HOST, _u64(seed), _u64(offset),
+            _stream()), "danra_edm_perturb")
+
+
+def edm_precondition(x, net_out, model_out, c_skip, c_out, clamp):
+    lib = load_library()
+    with torch.cuda.device(x.device):
+        _check(lib, lib.danra_edm_precondition(_ptr(_edm_plain(x, "x")), _ptr(_edm_plain(net_out, "net_out")),
+                                               _ptr(_edm_plain(model_out, "model_out")), ctypes.c_size_t(x.numel()), c_skip,
+                                               c_out, int(bool(clamp)), _stream()), "danra_edm_precondition")
+
+
+def edm_dynamic_threshold(x, percentile, out=None):
+    """s[b] = max(quantile(|x[b]|, percentile), 1): the reference's threshold_x_start up to the division."""
+    lib = load_library()
+    x = _edm_plain(x, "x")
+    B = x.shape[0]
+    s = torch.empty(B, device=x.device, dtype=torch.float32) if out is None else _edm_plain(out, "out")
+    with torch.cuda.device(x.device):
+        _check(lib, lib.danra_edm_dynamic_threshold(_ptr(x), _ptr(s), B, ctypes.c_size_t(x[0].numel()), percentile, _stream()),
+               "danra_edm_dynamic_threshold")
+    return s
+
+
+def edm_euler(images_hat, net_out, model_out, thresholds, d, images_next, net_in_next, c_skip, c_out, clamp, sigma_hat, dt,
+              c_in_next):
+    lib = load_library()
+    B = images_hat.shape[0]
+    with torch.cuda.device(images_hat.device):
+        _check(lib, lib.danra_edm_euler(
+            _ptr(_edm_plain(images_hat, "images_hat")), _ptr(_edm_plain(net_out, "net_out")),
+            _ptr(_edm_plain(model_out, "model_out")), _ptr(_edm_plain(thresholds, "thresholds")), _ptr(_edm_plain(d, "d")),
+            _ptr(_edm_plain(images_next, "images_next")), _ptr(_edm_plain(net_in_next, "net_in_next")), B,
+            ctypes.c_size_t(images_hat[0].numel()), c_skip, c_out, int(bool(clamp)), sigma_hat, dt, c_in_next, _stream()),
+            "danra_edm_euler")
+
+
+def edm_heun(images_hat, images_next, net_out, model_out, thresholds, d, images_out, c_skip, c_out, clamp, sigma_next,
+             half_dt):
+    lib = load_library()
+    B = images_hat.shape[0]
+    with torch.cuda.device(images_hat.device):
+        _check(lib, lib.danra_edm_heun(
+            _ptr(_edm_plain(images_hat, "images_hat")), _ptr(_edm_plain(images_next, "images_next")),
+            _ptr(_edm_plain(net_out, "net_out")), _ptr(_edm_plain(model_out, "model_out")),
+            _ptr(_edm_plain(thresholds, "thresholds")), _ptr(_edm_plain(d, "d")), _ptr(_edm_plain(images_out, "images_out")),
+            B, ctypes.c_size_t(images_hat[0].numel()), c_skip, c_out, int(bool(clamp)), sigma_next, half_dt, _stream()),
+            "danra_edm_heun")
+
+
+def edm_renoise(images, scale, noise=None, seed=0, offset=0):
+    lib = load_library()
+    with torch.cuda.device(images.device):
+        _check(lib, lib.danra_edm_renoise(_ptr(_edm_plain(images, "images")), _ptr(_edm_plain(noise, "noise")),
+                                          ctypes.c_size_t(images.numel()), scale,
+                                          NOISE_PHILOX if noise is None else NOISE_HOST, _u64(seed), _u64(offset), _stream()),
+               "danra_edm_renoise")
+
+
+def edm_finish(images, unnormalize, inpaint=None, mask=None):
+    lib = load_library()
+    B, C, HW = _edm_dims(_edm_plain(images, "images"))
+    with torch.cuda.device(images.device):
+        _check(lib, lib.danra_edm_finish(_ptr(images), _ptr(_edm_plain(inpaint, "inpaint")), _ptr(_edm_mask(mask, images)),
+                                         B, C, HW, int(bool(unnormalize)), _stream()), "danra_edm_finish")

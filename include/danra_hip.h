@@ -354,6 +354,47 @@ int danra_instance_norm(const float* x_nhwc, float* out_nhwc, int B, int HW, int
  * streams or threads) race; calls on one stream are ordered.  The array's address is resolved once per device, by
  * danra_create or by the first call on that device (which must therefore not be made under stream capture). */
 int danra_instance_norm_noalloc(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
+/* ---- The elucidated (Karras et al., EDM) sampler of the cascaded model: the arithmetic of one sampling step around
+ * the network evaluations (CascadedDDPM/elucidated_imagen.py:393-545, ElucidatedImagen.one_unet_sample).  Images are
+ * NCHW fp32 on the device, [B][C][HW]; an inpainting mask is one byte per image and pixel, [B][HW], shared by the
+ * channels (the reference's `b 1 h w` boolean, :462).  The network itself is the caller's: between these calls it
+ * maps net_in to net_out.  Scalars (c_in, c_skip, c_out of :325-332, step sizes) are formed by the host exactly as the
+ * reference forms them and passed as floats.  Every statement is evaluated in fp32, one rounding per operation, in the
+ * reference's order. */
+/* :489-499 and :359.  eps = s_noise * z; added = noise_scale * eps (noise_scale = sqrt(sigma_hat^2 - sigma^2));
+ * images_hat = images + added, with inpaint + added in the masked pixels when inpaint/mask are given (both or neither);
+ * net_in = c_in * images_hat.  z is read from noise_dev (DANRA_NOISE_HOST) or drawn from Philox(seed, offset). */
+int danra_edm_perturb(const float* images_dev, const float* noise_dev, const float* inpaint_dev,
+                      const unsigned char* mask_dev, float* images_hat_dev, float* net_in_dev, int B, int C, int HW,
+                      float s_noise, float noise_scale, float c_in, int noise_mode, uint64_t seed, uint64_t offset,
+                      void* stream);
+/* preconditioned_network_forward, :364-367 (+ :311 when clamp != 0): model_out = c_skip * x + c_out * net_out,
+ * clamped to [-1, 1] if `clamp`.  Used on its own when a dynamic threshold must be taken from model_out before the
+ * step; otherwise danra_edm_euler / danra_edm_heun form it themselves from net_out. */
+int danra_edm_precondition(const float* x_dev, const float* net_out_dev, float* model_out_dev, size_t n, float c_skip,
+                           float c_out, int clamp, void* stream);
+/* threshold_x_start, :313-319: s[b] = max(quantile(|x[b]|, percentile), 1) with torch.quantile's linear
+ * interpolation between the two neighbouring order statistics, which are found exactly (radix select). */
+int danra_edm_dynamic_threshold(const float* x_dev, float* s_dev, int B, size_t per_image, float percentile, void* stream);
+/* :509-511 (+ :321, :359).  model_out: formed from net_out_dev as in danra_edm_precondition when net_out_dev is given,
+ * else read from model_out_dev; thresholds_dev (nullable, one float per image) applies clamp(-s, s) / s to it; the
+ * result is written back to model_out_dev.  d = (images_hat - model_out) / sigma_hat (to d_dev, nullable);
+ * images_next = images_hat + dt * d; net_in_next = c_in_next * images_next (nullable: the last step). */
+int danra_edm_euler(const float* images_hat_dev, const float* net_out_dev, float* model_out_dev,
+                    const float* thresholds_dev, float* d_dev, float* images_next_dev, float* net_in_next_dev, int B,
+                    size_t per_image, float c_skip, float c_out, int clamp, float sigma_hat, float dt, float c_in_next,
+                    void* stream);
+/* :520-529.  model_out (of the evaluation at images_next, sigma_next) as in danra_edm_euler, with images_next as x;
+ * d' = (images_next - model_out) / sigma_next; images = images_hat + half_dt * (d + d'). */
+int danra_edm_heun(const float* images_hat_dev, const float* images_next_dev, const float* net_out_dev,
+                   float* model_out_dev, const float* thresholds_dev, const float* d_dev, float* images_dev, int B,
+                   size_t per_image, float c_skip, float c_out, int clamp, float sigma_next, float half_dt, void* stream);
+/* :535-536 (repaint): images += scale * z. */
+int danra_edm_renoise(float* images_dev, const float* noise_dev, size_t n, float scale, int noise_mode, uint64_t seed,
+                      uint64_t offset, void* stream);
+/* :540-545: clamp to [-1, 1]; inpaint in the masked pixels (both or neither); (x + 1) / 2 if `unnormalize`. */
+int danra_edm_finish(float* images_dev, const float* inpaint_dev, const unsigned char* mask_dev, int B, int C, int HW,
+                     int unnormalize, void* stream);
 /* NCHW <-> NHWC helpers for the tests. */
 int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream);
 int danra_nhwc_to_nchw(const float* src, float* dst, int B, int C, int HW, void* stream);
