@@ -1801,11 +1801,19 @@ int danra_edm_precondition(const float* x, const float* net_out, float* model_ou
     return DANRA_OK;
 }
 
-int danra_edm_dynamic_threshold(const float* x, float* s_out, int B, size_t per_image, float percentile, void* stream) {
+size_t danra_edm_dynamic_threshold_workspace(int B, size_t per_image) {
+    if (B <= 0 || per_image == 0) return 0;
+    return edm_quantile_workspace_bytes(B, per_image);
+}
+
+int danra_edm_dynamic_threshold(const float* x, float* s_out, int B, size_t per_image, float percentile, void* workspace,
+                                void* stream) {
     if (!x || !s_out) return fail(DANRA_EINVAL, "null argument");
     RC_TRY(edm_image_args(B, per_image));
     if (!(percentile >= 0.f && percentile <= 1.f)) return fail(DANRA_EINVAL, "percentile %g is outside [0, 1]", (double)percentile);
-    HIP_TRY(launch_edm_quantile_abs(x, s_out, B, per_image, percentile, 1.0f, (hipStream_t)stream));
+    if (!workspace && edm_quantile_workspace_bytes(B, per_image))
+        return fail(DANRA_EINVAL, "images of %zu values need a workspace of danra_edm_dynamic_threshold_workspace() bytes", per_image);
+    HIP_TRY(launch_edm_quantile_abs(x, s_out, B, per_image, percentile, 1.0f, workspace, (hipStream_t)stream));
     return DANRA_OK;
 }
 

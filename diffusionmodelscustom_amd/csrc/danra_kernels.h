@@ -218,8 +218,10 @@ hipError_t launch_edm_perturb(const float* images, const float* noise, const flo
                               int philox, uint64_t seed, uint64_t offset, hipStream_t stream);
 hipError_t launch_edm_precondition(const float* x, const float* net, float* out, size_t n, float c_skip, float c_out,
                                    int clamp, hipStream_t stream);
+// workspace: edm_quantile_workspace_bytes(B, per_image) bytes (0 for small images: then it may be null)
+size_t edm_quantile_workspace_bytes(int B, size_t per_image);
 hipError_t launch_edm_quantile_abs(const float* x, float* out, int B, size_t per_image, float q, float floor_value,
-                                   hipStream_t stream);
+                                   void* workspace, hipStream_t stream);
 hipError_t launch_edm_euler(const float* images_hat, const float* net, float* model_out, const float* thr, float* d_out,
                             float* images_next, float* net_in_next, int B, size_t per_image, float c_skip, float c_out,
                             int clamp, float sigma_hat, float dt, float c_in_next, hipStream_t stream);

@@ -10,6 +10,7 @@
 // the reference does.  The exception is the dynamic threshold, a per-image order statistic: one workgroup per image
 // finds it with an exact radix select over the bit patterns of |x| (no sort, no approximation).
 #include <initializer_list>
+#include <type_traits>
 
 #include "danra_kernels.h"
 #include "philox_noise.h"
@@ -142,104 +143,247 @@ __global__ __launch_bounds__(256) void k_edm_precondition(const float* __restric
 
 // ---- dynamic threshold: s[b] = max(quantile(|x[b]|, q), floor_value) with torch.quantile's linear interpolation
 // (elucidated_imagen.py:313-319).  The order statistics sorted[floor(rank)] and sorted[ceil(rank)], rank = q (n - 1)
-// in fp32, are found exactly: for x >= 0 the bit pattern of a float orders like the float, so four passes over the
-// image, each fixing eight more bits of the wanted key from a 256-bin histogram of the candidates that still match,
-// select the element of a given rank; a fifth pass finds the next larger key when the upper rank lies beyond the run
-// of equal keys.  One workgroup per image; passes after the first read the image from the L2.
-template <int V>
-__global__ __launch_bounds__(1024) void k_edm_quantile_abs(const float* __restrict__ x, float* __restrict__ out, size_t n,
-                                                           float q, float floor_value) {
+// in fp32, are found exactly, without sorting: for x >= 0 the bit pattern of a float orders like the float, so three
+// passes over the image - each fixing the next 11, 10, 10 bits of the wanted 31-bit key from a histogram of the
+// candidates that still match the bits fixed so far - select the element of rank floor(rank).  Its upper neighbour
+// is the same key (inside a run of equal values), else the next occupied bin of the last histogram, else the
+// smallest key with larger high bits, which the last pass collects on the way.
+// Small images: one workgroup per image does the three passes in one launch (k_edm_quantile_abs).  Large images: the
+// image is cut in slices over many workgroups and every pass is a launch of its own (k_edm_quantile_pass): a workgroup
+// counts its slice in LDS, adds its non-empty bins to the image's histogram in the workspace, and the workgroups of
+// the NEXT launch each repeat the (cheap) bin selection from it, so no workgroup waits for another inside a launch.
+constexpr int Q_WORDS = 3 * 2048 + 8;  // workspace words per image: three histograms, then {smallest larger key, NaN seen}
+constexpr int Q_MIN = 3 * 2048, Q_NAN = 3 * 2048 + 1;
+__host__ __device__ constexpr int q_bins(int pass) { return pass == 0 ? 2048 : 1024; }
+__host__ __device__ constexpr int q_shift(int pass) { return pass == 0 ? 20 : pass == 1 ? 10 : 0; }
+__host__ __device__ constexpr unsigned q_fixed(int pass) { return pass == 0 ? 0u : pass == 1 ? 0x7ff00000u : 0x7ffffc00u; }
+
+struct QRank {
+    float rank, rank_lo;
+    unsigned lower, upper;
+};
+__device__ __forceinline__ QRank q_rank(float q, size_t n) {
 #pragma clang fp contract(off)
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sel[3];   // chosen bin, rank inside it, its count
-    __shared__ unsigned above;    // smallest key larger than the selected one
-    __shared__ int saw_nan;
-    const float* img = x + (size_t)blockIdx.x * n;
-    const size_t units = n / V;
-    const int tid = threadIdx.x;
-    const float rank = q * (float)(n - 1);
-    const float rank_lo = floorf(rank);
-    const unsigned lower = (unsigned)rank_lo, upper = (unsigned)ceilf(rank);
-    if (tid == 0) {
-        saw_nan = 0;
-        above = 0xffffffffu;
+    QRank r;
+    r.rank = q * (float)(n - 1);
+    r.rank_lo = floorf(r.rank);
+    r.lower = (unsigned)r.rank_lo;
+    r.upper = (unsigned)ceilf(r.rank);
+    return r;
+}
+
+// Lanes 0-63 of a workgroup together: the bin of `hist` (NBINS counts, LDS or global, 16-byte aligned) that holds
+// rank r -> sel = {bin, rank inside the bin, count of the bin}.  A lane fetches its NBINS / 64 consecutive counts with
+// 16-byte loads, all in flight at once, and keeps them in registers for the search inside its range.
+template <int NBINS>
+__device__ __forceinline__ void q_select(const unsigned* hist, unsigned r, unsigned* sel) {
+    constexpr int PER = NBINS / 64;
+    const int lane = threadIdx.x;
+    uint4 c4[PER / 4];
+#pragma unroll
+    for (int j = 0; j < PER / 4; ++j) c4[j] = reinterpret_cast<const uint4*>(hist + lane * PER)[j];
+    unsigned c[PER];
+#pragma unroll
+    for (int j = 0; j < PER / 4; ++j) {
+        c[4 * j] = c4[j].x; c[4 * j + 1] = c4[j].y; c[4 * j + 2] = c4[j].z; c[4 * j + 3] = c4[j].w;
     }
-    unsigned prefix = 0, fixed = 0, r = lower;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (size_t u = tid; u < units; u += 1024) {
-            const Pack<V> v = ld<V>(img, u);
+    unsigned s = 0;
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const unsigned key = __float_as_uint(v.v[j]) & 0x7fffffffu;
-                if (pass == 0 && key > 0x7f800000u) saw_nan = 1;
-                if ((key & fixed) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {  // the bin that holds rank r: lane l owns bins 4l .. 4l+3
-            unsigned h[4], s = 0;
+    for (int j = 0; j < PER; ++j) s += c[j];
+    unsigned incl = s;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h[j] = hist[4 * tid + j];
-                s += h[j];
-            }
-            unsigned incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(incl, o);
-                if (tid >= o) incl += t;
-            }
-            unsigned cum = incl - s;
-            if (cum <= r && r < incl) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (r >= cum && r < cum + h[j]) {
-                        sel[0] = 4 * tid + j;
-                        sel[1] = r - cum;
-                        sel[2] = h[j];
-                    }
-                    cum += h[j];
-                }
-            }
-        }
-        __syncthreads();
-        prefix |= sel[0] << shift;
-        fixed |= 255u << shift;
-        r = sel[1];
-        __syncthreads();  // sel and hist are rewritten by the next pass
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
     }
-    const unsigned run = sel[2];  // elements equal to the selected key; r = position of `lower` inside that run
-    const bool need_above = upper != lower && r + 1 >= run;
-    if (need_above) {
-        unsigned best = 0xffffffffu;
-        for (size_t u = tid; u < units; u += 1024) {
-            const Pack<V> v = ld<V>(img, u);
+    unsigned cum = incl - s;
+    if (cum <= r && r < incl) {
+        bool found = false;
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const unsigned key = __float_as_uint(v.v[j]) & 0x7fffffffu;
-                if (key > prefix && key < best) best = key;
+        for (int j = 0; j < PER; ++j) {
+            if (!found && r < cum + c[j]) {
+                sel[0] = lane * PER + j;
+                sel[1] = r - cum;
+                sel[2] = c[j];
+                found = true;
             }
+            cum += c[j];
         }
+    }
+}
+
+// Lanes 0-63: smallest occupied bin above `bin` in the last pass's histogram, or 0xffffffff.
+__device__ __forceinline__ unsigned q_next_bin(const unsigned* hist, unsigned bin) {
+    const int lane = threadIdx.x;
+    constexpr int per = q_bins(2) / 64;
+    unsigned best = 0xffffffffu;
+    for (int j = per - 1; j >= 0; --j) {
+        const unsigned t = lane * per + j;
+        if (t > bin && hist[t]) best = t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(best, o);
+        best = t < best ? t : best;
+    }
+    return best;
+}
+
+// Counts units [u_begin, u_end) of an image into the LDS histogram of pass PASS.
+template <int V, int PASS>
+__device__ __forceinline__ void q_accumulate(const float* __restrict__ img, size_t u_begin, size_t u_end, unsigned prefix,
+                                             unsigned* hist, unsigned* lds_min, int* lds_nan) {
+    constexpr unsigned fixed = q_fixed(PASS), binmask = q_bins(PASS) - 1;
+    constexpr int shift = q_shift(PASS);
+    unsigned best = 0xffffffffu;
+    bool nan = false;
+    for (size_t u = u_begin + threadIdx.x; u < u_end; u += blockDim.x) {
+        const Pack<V> v = ld<V>(img, u);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const unsigned key = __float_as_uint(v.v[j]) & 0x7fffffffu;
+            if (PASS == 0 && key > 0x7f800000u) nan = true;
+            if ((key & fixed) == prefix) atomicAdd(&hist[(key >> shift) & binmask], 1u);
+            // the low bits of `prefix` are still zero: a key above it that differs in the fixed bits has larger high bits
+            else if (PASS == 2 && key > prefix && key < best) best = key;
+        }
+    }
+    if (PASS == 0 && nan) *lds_nan = 1;
+    if (PASS == 2) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned t = __shfl_xor(best, o);
             best = t < best ? t : best;
         }
-        if ((tid & 63) == 0) atomicMin(&above, best);
+        if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(lds_min, best);
+    }
+}
+
+// key of rank `lower` (with r = its position inside the run of `run` equal keys), the key above it, NaN flag -> s
+__device__ __forceinline__ float q_finish(const QRank& rk, unsigned key_lo, unsigned key_above, bool nan, float floor_value) {
+#pragma clang fp contract(off)
+    const float v_lo = __uint_as_float(key_lo);
+    const float v_hi = rk.upper != rk.lower ? __uint_as_float(key_above) : v_lo;
+    const float w = rk.rank - rk.rank_lo;
+    const float diff = v_hi - v_lo;
+    float s = w < 0.5f ? v_lo + w * diff : v_hi - diff * (1.0f - w);  // torch.lerp
+    if (nan) s = __uint_as_float(0x7fc00000u);
+    return s < floor_value ? floor_value : s;  // clamp_(min): NaN stays
+}
+
+template <int V>
+__global__ __launch_bounds__(1024) void k_edm_quantile_abs(const float* __restrict__ x, float* __restrict__ out, size_t n,
+                                                           float q, float floor_value) {
+    __shared__ __attribute__((aligned(16))) unsigned hist[2048];
+    __shared__ unsigned sel[3];
+    __shared__ unsigned lds_min;
+    __shared__ int lds_nan;
+    const float* img = x + (size_t)blockIdx.x * n;
+    const size_t units = n / V;
+    const int tid = threadIdx.x;
+    const QRank rk = q_rank(q, n);
+    if (tid == 0) {
+        lds_nan = 0;
+        lds_min = 0xffffffffu;
+    }
+    unsigned prefix = 0, r = rk.lower;
+    auto pass = [&](auto tag) {
+        constexpr int PASS = decltype(tag)::value;
+        for (int t = tid; t < q_bins(PASS); t += 1024) hist[t] = 0;
+        __syncthreads();
+        q_accumulate<V, PASS>(img, 0, units, prefix, hist, &lds_min, &lds_nan);
+        __syncthreads();
+        if (tid < 64) q_select<q_bins(PASS)>(hist, r, sel);
+        __syncthreads();
+        prefix |= sel[0] << q_shift(PASS);
+        r = sel[1];
+        if (PASS < 2) __syncthreads();  // hist and sel are rewritten by the next pass
+    };
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    pass(std::integral_constant<int, 2>{});
+    if (tid < 64) {
+        unsigned above = prefix;
+        if (r + 1 >= sel[2]) {  // the upper rank lies beyond the run of equal keys
+            const unsigned nb = q_next_bin(hist, sel[0]);
+            above = nb != 0xffffffffu ? ((prefix & q_fixed(2)) | nb) : lds_min;
+        }
+        if (tid == 0) out[blockIdx.x] = q_finish(rk, prefix, above, lds_nan != 0, floor_value);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_edm_quantile_init(unsigned* __restrict__ ws, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        ws[i] = (i % Q_WORDS) == Q_MIN ? 0xffffffffu : 0u;
+}
+
+// The selections of the passes before PASS, from the image's histograms in the workspace (lanes 0-63 select, all
+// threads of the workgroup receive): prefix = the key bits fixed so far, r = the rank among the remaining candidates.
+template <int PASS>
+__device__ __forceinline__ void q_replay(const unsigned* ws_img, unsigned lower, unsigned* sel, unsigned& prefix, unsigned& r) {
+    prefix = 0;
+    r = lower;
+#pragma unroll
+    for (int p = 0; p < PASS; ++p) {
+        if (threadIdx.x < 64) {
+            if (p == 0) q_select<q_bins(0)>(ws_img, r, sel);
+            else q_select<q_bins(1)>(ws_img + p * 2048, r, sel);
+        }
+        __syncthreads();
+        prefix |= sel[0] << q_shift(p);
+        r = sel[1];
         __syncthreads();
     }
+}
+
+template <int V, int PASS>
+__global__ __launch_bounds__(512) void k_edm_quantile_pass(const float* __restrict__ x, unsigned* __restrict__ ws, size_t n,
+                                                           float q) {
+    __shared__ __attribute__((aligned(16))) unsigned hist[2048];
+    __shared__ unsigned sel[3];
+    __shared__ unsigned lds_min;
+    __shared__ int lds_nan;
+    const int tid = threadIdx.x;
+    const float* img = x + (size_t)blockIdx.y * n;
+    unsigned* ws_img = ws + (size_t)blockIdx.y * Q_WORDS;
+    const QRank rk = q_rank(q, n);
+    unsigned prefix, r;
+    q_replay<PASS>(ws_img, rk.lower, sel, prefix, r);
+    for (int t = tid; t < q_bins(PASS); t += 512) hist[t] = 0;
     if (tid == 0) {
-        const float v_lo = __uint_as_float(prefix);
-        const float v_hi = need_above ? __uint_as_float(above) : v_lo;
-        const float w = rank - rank_lo;
-        const float diff = v_hi - v_lo;
-        float s = w < 0.5f ? v_lo + w * diff : v_hi - diff * (1.0f - w);  // torch.lerp
-        if (saw_nan) s = __uint_as_float(0x7fc00000u);
-        out[blockIdx.x] = s < floor_value ? floor_value : s;  // clamp_(min): NaN stays
+        lds_nan = 0;
+        lds_min = 0xffffffffu;
     }
+    __syncthreads();
+    const size_t units = n / V;
+    const size_t per = (units + gridDim.x - 1) / gridDim.x;
+    const size_t begin = (size_t)blockIdx.x * per;
+    const size_t end = begin + per < units ? begin + per : units;
+    q_accumulate<V, PASS>(img, begin, end, prefix, hist, &lds_min, &lds_nan);
+    __syncthreads();
+    for (int t = tid; t < q_bins(PASS); t += 512) {
+        const unsigned c = hist[t];
+        if (c) atomicAdd(&ws_img[PASS * 2048 + t], c);
+    }
+    if (tid == 0) {
+        if (PASS == 0 && lds_nan) atomicOr(&ws_img[Q_NAN], 1u);
+        if (PASS == 2 && lds_min != 0xffffffffu) atomicMin(&ws_img[Q_MIN], lds_min);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_edm_quantile_result(const unsigned* __restrict__ ws, float* __restrict__ out, size_t n,
+                                                            float q, float floor_value) {
+    __shared__ unsigned sel[3];
+    const unsigned* ws_img = ws + (size_t)blockIdx.x * Q_WORDS;
+    const QRank rk = q_rank(q, n);
+    unsigned prefix, r;
+    q_replay<3>(ws_img, rk.lower, sel, prefix, r);
+    unsigned above = prefix;
+    if (r + 1 >= sel[2]) {
+        const unsigned nb = q_next_bin(ws_img + 2 * 2048, sel[0]);
+        above = nb != 0xffffffffu ? ((prefix & q_fixed(2)) | nb) : ws_img[Q_MIN];
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = q_finish(rk, prefix, above, ws_img[Q_NAN] != 0, floor_value);
 }
 
 // ---- Euler step.  model_out: with `net` the preconditioned network output is formed here and written; without, the
@@ -422,13 +566,45 @@ hipError_t launch_edm_precondition(const float* x, const float* net, float* out,
     return hipGetLastError();
 }
 
+// Images above this many values are cut in slices over several workgroups (one launch per pass, workspace needed).
+static constexpr size_t Q_SINGLE_MAX = 32768;
+static int q_slices(int B, size_t per_image, int V) {
+    const size_t units = per_image / V;
+    size_t s = (size_t)(1024 + B - 1) / B;               // about a thousand workgroups in all
+    const size_t most = (units + 511) / 512;              // at least one unit per thread
+    if (s > most) s = most;
+    return (int)(s < 1 ? 1 : s);
+}
+
+size_t edm_quantile_workspace_bytes(int B, size_t per_image) {
+    return per_image <= Q_SINGLE_MAX ? 0 : (size_t)B * Q_WORDS * sizeof(unsigned);
+}
+
 hipError_t launch_edm_quantile_abs(const float* x, float* out, int B, size_t per_image, float q, float floor_value,
-                                   hipStream_t stream) {
+                                   void* workspace, hipStream_t stream) {
     const int V = edm_width(per_image, 4, {x});
-    if (V == 4)
-        hipLaunchKernelGGL(k_edm_quantile_abs<4>, dim3(B), dim3(1024), 0, stream, x, out, per_image, q, floor_value);
-    else
-        hipLaunchKernelGGL(k_edm_quantile_abs<1>, dim3(B), dim3(1024), 0, stream, x, out, per_image, q, floor_value);
+    if (per_image <= Q_SINGLE_MAX) {
+        if (V == 4)
+            hipLaunchKernelGGL(k_edm_quantile_abs<4>, dim3(B), dim3(1024), 0, stream, x, out, per_image, q, floor_value);
+        else
+            hipLaunchKernelGGL(k_edm_quantile_abs<1>, dim3(B), dim3(1024), 0, stream, x, out, per_image, q, floor_value);
+        return hipGetLastError();
+    }
+    if (!workspace) return hipErrorInvalidValue;
+    unsigned* ws = static_cast<unsigned*>(workspace);
+    const size_t words = (size_t)B * Q_WORDS;
+    hipLaunchKernelGGL(k_edm_quantile_init, dim3(grid_for(words)), dim3(256), 0, stream, ws, words);
+    const dim3 grid(q_slices(B, per_image, V), B);
+    if (V == 4) {
+        hipLaunchKernelGGL((k_edm_quantile_pass<4, 0>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+        hipLaunchKernelGGL((k_edm_quantile_pass<4, 1>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+        hipLaunchKernelGGL((k_edm_quantile_pass<4, 2>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+    } else {
+        hipLaunchKernelGGL((k_edm_quantile_pass<1, 0>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+        hipLaunchKernelGGL((k_edm_quantile_pass<1, 1>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+        hipLaunchKernelGGL((k_edm_quantile_pass<1, 2>), grid, dim3(512), 0, stream, x, ws, per_image, q);
+    }
+    hipLaunchKernelGGL(k_edm_quantile_result, dim3(B), dim3(64), 0, stream, ws, out, per_image, q, floor_value);
     return hipGetLastError();
 }
 

@@ -112,7 +112,8 @@ _SIGNATURES = {
     "danra_edm_perturb": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_uint64,
                                                                                               ctypes.c_uint64, _P]),
     "danra_edm_precondition": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int, _P]),
-    "danra_edm_dynamic_threshold": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, _P]),
+    "danra_edm_dynamic_threshold_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_size_t]),
+    "danra_edm_dynamic_threshold": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, _P, _P]),
     "danra_edm_euler": (ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     "danra_edm_heun": (ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_int,
@@ -962,9 +963,12 @@ def edm_dynamic_threshold(x, percentile, out=None):
     x = _edm_plain(x, "x")
     B = x.shape[0]
     s = torch.empty(B, device=x.device, dtype=torch.float32) if out is None else _edm_plain(out, "out")
+    per_image = x[0].numel()
+    nbytes = lib.danra_edm_dynamic_threshold_workspace(B, ctypes.c_size_t(per_image))
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
-        _check(lib, lib.danra_edm_dynamic_threshold(_ptr(x), _ptr(s), B, ctypes.c_size_t(x[0].numel()), percentile, _stream()),
-               "danra_edm_dynamic_threshold")
+        _check(lib, lib.danra_edm_dynamic_threshold(_ptr(x), _ptr(s), B, ctypes.c_size_t(per_image), percentile, _ptr(ws),
+                                                    _stream()), "danra_edm_dynamic_threshold")
     return s
 
 

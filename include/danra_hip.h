@@ -374,8 +374,12 @@ int danra_edm_perturb(const float* images_dev, const float* noise_dev, const flo
 int danra_edm_precondition(const float* x_dev, const float* net_out_dev, float* model_out_dev, size_t n, float c_skip,
                            float c_out, int clamp, void* stream);
 /* threshold_x_start, :313-319: s[b] = max(quantile(|x[b]|, percentile), 1) with torch.quantile's linear
- * interpolation between the two neighbouring order statistics, which are found exactly (radix select). */
-int danra_edm_dynamic_threshold(const float* x_dev, float* s_dev, int B, size_t per_image, float percentile, void* stream);
+ * interpolation between the two neighbouring order statistics, which are found exactly (radix select).
+ * workspace_dev: danra_edm_dynamic_threshold_workspace(B, per_image) bytes of device memory, contents irrelevant before
+ * and after the call (0 bytes for images of at most 32768 values: then it may be null). */
+size_t danra_edm_dynamic_threshold_workspace(int B, size_t per_image);
+int danra_edm_dynamic_threshold(const float* x_dev, float* s_dev, int B, size_t per_image, float percentile,
+                                void* workspace_dev, void* stream);
 /* :509-511 (+ :321, :359).  model_out: formed from net_out_dev as in danra_edm_precondition when net_out_dev is given,
  * else read from model_out_dev; thresholds_dev (nullable, one float per image) applies clamp(-s, s) / s to it; the
  * result is written back to model_out_dev.  d = (images_hat - model_out) / sigma_hat (to d_dev, nullable);

@@ -107,7 +107,7 @@ def test_step_kernels_bit_equal_the_reference_statements(shape):
             assert torch.equal(x.cpu(), want)
 
 
-@pytest.mark.parametrize("n", [1, 7, 105, 768, 12288, 196608])
+@pytest.mark.parametrize("n", [1, 7, 105, 768, 12288, 32768, 33333, 196608])
 def test_dynamic_threshold_is_the_exact_order_statistic(n):
     torch.manual_seed(n)
     rows = torch.randn(5, n) * 3
