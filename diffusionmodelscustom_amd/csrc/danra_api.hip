@@ -622,6 +622,7 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
             slabs->stride = (size_t)a.M * a.N;
             slabs->bias = c.bias;
             slabs->pix_major = a.pix_major;
+            slabs->ct_W = 0;
         }
     }
     RC_TRY(igemm(h, a, st));
@@ -788,8 +789,10 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     return DANRA_OK;
 }
 
+// slabs != null: if the GEMM is split over K, its reduction kernel is left out and *slabs describes the slabs (the
+// caller's InstanceNorm statistics kernel sums them and writes `out`); slabs->count stays 0 otherwise.
 int run_convT(danra_handle_s* h, const float* wt, const float* bt, int C, const float* in, float* out, int B, int Hh,
-              int Ww, hipStream_t st, const SplitW* split = nullptr) {
+              int Ww, hipStream_t st, const SplitW* split = nullptr, InSlabs* slabs = nullptr) {
     IGemmArgs a = blank_args();
     if (split) use_split(a, *split);
     a.A = in; a.lda = C; a.a_mode = A_GEMM;
@@ -797,6 +800,17 @@ int run_convT(danra_handle_s* h, const float* wt, const float* bt, int C, const 
     a.M = B * Hh * Ww; a.N = 4 * C; a.K = C;
     a.st_mode = ST_CONVT; a.ct_C = C; a.ct_H = Hh; a.ct_W = Ww;
     choose_split(a, h->ws);
+    if (slabs) {
+        slabs->count = 0;
+        if (a.ksplit > 1) {
+            a.keep_slabs = 1;
+            slabs->count = a.ksplit;
+            slabs->stride = (size_t)a.M * a.N;
+            slabs->bias = bt;  // (the packed bias repeats the C values for each of the four sub-pixels)
+            slabs->pix_major = 0;
+            slabs->ct_W = Ww;
+        }
+    }
     RC_TRY(igemm(h, a, st));
     return DANRA_OK;
 }
@@ -855,17 +869,28 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
+    // The first InstanceNorm: while an image's pixels fit the registers of the block that forms its statistics, that
+    // block also writes the normalised values back (in place) and the convolution reads a plain tensor.  Normalising
+    // in the convolution's operand loader instead costs it two more 16-byte loads (mean, 1/std) per activation load,
+    // and the loader is what its loop waits for: 19-21 us against 11 us per launch at 64 images.
+    bool normalised = false;
     if (!up_ready) {
-        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt));
-        HIP_TRY(launch_in_stats(ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats, B, H2 * W2, d.Cin, st));
+        InSlabs up_slabs{0, 0, nullptr, 0, 0};
+        static const int in_place_px = getenv("DANRA_IN_PLACE_PX") ? atoi(getenv("DANRA_IN_PLACE_PX")) : 64;
+        normalised = H2 * W2 <= in_place_px && H2 * W2 <= 1024;
+        // (... and when the transposed convolution is split over K, that block sums its slabs as well)
+        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt, normalised ? &up_slabs : nullptr));
+        HIP_TRY(launch_in_stats(up_slabs.count ? ws.partial : ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats,
+                                B, H2 * W2, d.Cin, st, normalised ? ws.up : nullptr, nullptr, nullptr, 0,
+                                up_slabs.count ? &up_slabs : nullptr));
     } else {  // the producer of ws.up left its statistics in slices of 32 samples
         HIP_TRY(launch_in_stats_from_slices(ws.stats_part, ws.mean1, ws.rstd1, B, Hh * Ww / 8, 32, st));
     }
     // second InstanceNorm + skip + time bias in one pass (the block that forms an image's statistics holds its pixels);
     // when the convolution is split over K and an image fits one block, that pass also sums the convolution's slabs
-    InSlabs slabs{0, 0, nullptr, 0};
-    RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, ws.mean1, ws.rstd1, st, nullptr,
-                    H2 * W2 <= 1024 ? &slabs : nullptr));
+    InSlabs slabs{0, 0, nullptr, 0, 0};
+    RC_TRY(run_conv(h, d.conv, ws.up, ws.cv, B, H2, W2, nullptr, 0, nullptr, normalised ? nullptr : ws.mean1,
+                    normalised ? nullptr : ws.rstd1, st, nullptr, H2 * W2 <= 1024 ? &slabs : nullptr));
     HIP_TRY(launch_in_stats(slabs.count ? ws.partial : ws.cv, ws.mean2, ws.rstd2, ws.stats_part, ws.stats_part_floats, B,
                             H2 * W2, d.Cout, st, ws.pre, skip, tbias ? tbias + d.tb_off : nullptr, h->tb_width,
                             slabs.count ? &slabs : nullptr));
@@ -904,9 +929,12 @@ int run_final_block(danra_handle_s* h, const float* in, float* eps_nchw, int B, 
 // `t` gives one timestep per image; with t == null every image uses the sampler state's current one.
 int forward_impl(danra_handle_s* h, const float* x, const int64_t* t, SampleState* state, const int64_t* y,
                  const float* cond, const float* lsm, const float* topo, float* eps, int B, int H, int W,
-                 hipStream_t st, bool stem_static_ready = false, const float* tb_table = nullptr) {
+                 hipStream_t st, bool stem_static_ready = false, const float* tb_table = nullptr,
+                 bool tbias_ready = false) {
     Workspace& ws = h->ws;
-    if (tb_table)  // sampling loop: the projections were tabulated for every timestep before the loop
+    if (tbias_ready) {
+        // sampling loop, one evaluation per step: the previous step's update kernel gathered this step's rows
+    } else if (tb_table)  // sampling loop: the projections were tabulated for every timestep before the loop
         HIP_TRY(launch_tbias_gather(state, tb_table, y, ws.tbias, h->cfg.num_classes > 0 && y ? h->cfg.num_classes : 1,
                                     h->tb_width, B, st));
     else
@@ -1482,13 +1510,18 @@ int danra_sample_guided(danra_handle_t h, float* x, const int64_t* y, const floa
         if (h->cfg.has_cond) planes[np++] = ws.conds;
         RC_TRY(run_stem_planes(h, planes, 1, np - 1, ws.stem_static, B, H, W, nullptr, nullptr, st));
     }
+    // One evaluation per step: the update kernel gathers the next step's time projections (the first step's are
+    // gathered here).  A guided step gathers twice, from different tables, at the head of each evaluation.
+    const NextGather next{h->tb_table, has_y ? ws.ys : nullptr, ws.tbias, classes, h->tb_width, B};
+    if (!guided) HIP_TRY(launch_tbias_gather(ws.state, h->tb_table, next.y, ws.tbias, classes, h->tb_width, B, st));
     auto enqueue_step = [&](hipStream_t s) -> int {
         RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, has_y ? ws.ys : nullptr, ws.conds, ws.lsms, ws.topos, ws.eps, B,
-                            H, W, s, true, h->tb_table));
+                            H, W, s, true, h->tb_table, !guided));
         if (guided)
             RC_TRY(forward_impl(h, ws.xs, nullptr, ws.state, nullptr, nullptr, nullptr, nullptr, ws.eps_uncond, B, H, W, s,
                                 true, tb_uncond));
-        HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, guided ? ws.eps_uncond : nullptr, ws.coef, ws.state, n, s));
+        HIP_TRY(launch_ddpm_update_state(ws.xs, ws.eps, guided ? ws.eps_uncond : nullptr, ws.coef, ws.state, n, s,
+                                         guided ? nullptr : &next));
         return DANRA_OK;
     };
 

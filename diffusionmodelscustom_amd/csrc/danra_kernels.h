@@ -129,7 +129,8 @@ hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float
 // ---------------------------------------------------------------- small kernels
 // Device-resident state of the sampling loop: one denoise step can be enqueued (or replayed from a
 // hipGraph) without any per-step host argument.  k_time_mlp reads t_fwd and publishes it as t_upd; the
-// update kernel reads t_upd and publishes t_upd - 1 as t_fwd, so no kernel reads a field it writes.
+// update kernel reads t_upd and publishes t_upd - 1 as t_fwd, so no kernel reads a field it writes (the update
+// kernel that also gathers the next step's time projections is the exception, see NextGather).
 struct SampleState {
     int t_fwd;                 // timestep of the next UNet evaluation
     int t_upd;                 // timestep of the next update
@@ -140,13 +141,23 @@ struct SampleState {
     float cfg_scale;           // classifier-free guidance weight (used when the update is given two predictions)
     float noise_scale;         // every draw is multiplied by this (1, or 0.005 for the "scaled data" mode)
     unsigned long long quad_offset;  // Philox counter of this call's first element quad (a batch slice of a larger batch)
+    unsigned int ticket;       // blocks of the update kernel that are done (the last one hands the timestep over)
+};
+// What launch_tbias_gather does for the next evaluation, as a tail of the update kernel.
+struct NextGather {
+    const float* table;        // [T][classes][width] time projections
+    const int64_t* y;          // [B] labels or null
+    float* tbias;              // [B][width]
+    int classes, width, B;
 };
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,
                              float cfg_scale, float noise_scale, unsigned long long quad_offset, hipStream_t stream);
 // x <- c1*(x - c2*eps) + c3*(noise_scale*z) with (c1, c2, c3) = coef[state->t_upd] and z = 0 at timestep 1.
 // With eps_uncond != null, eps is first replaced by lerp(eps_uncond, eps, cfg_scale).
+// With `next` the kernel also gathers tbias for the evaluation at timestep t_upd - 1 and publishes that timestep as
+// t_upd as well as t_fwd (no gather kernel runs at the head of the next step).
 hipError_t launch_ddpm_update_state(float* x, const float* eps, const float* eps_uncond, const float4* coef,
-                                    SampleState* state, size_t n, hipStream_t stream);
+                                    SampleState* state, size_t n, hipStream_t stream, const NextGather* next = nullptr);
 
 struct TimeMlpArgs {
     const int64_t* t;          // [B], or null when `state` supplies one timestep for every row
@@ -179,6 +190,8 @@ struct InSlabs {
     size_t stride;      // floats between slabs (M * N of the GEMM)
     const float* bias;  // [C] or null
     int pix_major;      // row order of the GEMM
+    int ct_W;           // != 0: the GEMM is a kernel-2 stride-2 transposed convolution on a map ct_W pixels wide (rows = coarse
+                        // pixels, columns = (dy, dx, channel)); needs `out`, which then receives the normalised tensor
 };
 hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part, size_t part_floats, int B, int HW,
                            int C, hipStream_t stream, float* out = nullptr, const float* skip = nullptr,

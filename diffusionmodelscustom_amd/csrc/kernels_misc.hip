@@ -206,19 +206,20 @@ hipError_t launch_tbias_gather(SampleState* state, const float* table, const int
 // With gridDim.z = S > 1 the pixels are cut into S equal slices; each block then writes the mean and the
 // centred sum of squares of its slice to part[b][s][{mean, m2}][C] and k_in_stats_merge combines them
 // (Chan et al.'s pairwise update with equal counts), which keeps the two-pass accuracy.
+template <int CQ>
 __device__ __forceinline__ float4 block_sum_by_quad(float4 v, float4* red, int tid) {
-    // threads with equal (tid & 7) hold the same four channels: 8 per wave, 4 waves
+    // threads with equal (tid & (CQ - 1)) hold the same four channels: 64 / CQ per wave, 4 waves
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = CQ; o < 64; o <<= 1) {
         v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
     }
     __syncthreads();  // the previous use of `red` has been read
-    if ((tid & 63) < 8) red[(tid >> 6) * 8 + (tid & 7)] = v;
+    if ((tid & 63) < CQ) red[(tid >> 6) * CQ + (tid & (CQ - 1))] = v;
     __syncthreads();
-    float4 r = red[tid & 7];
+    float4 r = red[tid & (CQ - 1)];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-        const float4 o = red[w * 8 + (tid & 7)];
+        const float4 o = red[w * CQ + (tid & (CQ - 1))];
         r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
     }
     return r;
@@ -226,32 +227,44 @@ __device__ __forceinline__ float4 block_sum_by_quad(float4 v, float4* red, int t
 
 // With `out` set (unsliced launches only) the block also applies the normalisation to the values it holds:
 // out = (x - mean) * rstd [+ skip] [+ tbias[image][channel]], the tail of a decoder block before its attention.
-template <int NP>
-__global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, float* __restrict__ mean,
+// `out` may be `x` itself (neither is declared restrict): a block has all its values in registers before its first store
+// and no other block reads them.
+// CQ = channel quads of a block: 8 (32 channels x 32 pixel slots) or 4 (16 channels x 64 pixel slots, twice the blocks
+// with half the registers each, for launches that would otherwise leave half of the chip idle).
+template <int NP, int CQ = 8>
+__global__ __launch_bounds__(256) void k_in_stats(const float* x, float* __restrict__ mean,
                                                   float* __restrict__ rstd, float* __restrict__ part, int HWtotal,
-                                                  int C, float* __restrict__ out, const float* __restrict__ skip,
+                                                  int C, float* out, const float* __restrict__ skip,
                                                   const float* __restrict__ tbias, int tb_stride, int n_slabs,
                                                   size_t slab_stride, const float* __restrict__ slab_bias,
-                                                  size_t img_stride, size_t pix_stride) {
+                                                  size_t img_stride, size_t pix_stride, int ct_W) {
     __shared__ float4 red[32];
     const int b = blockIdx.x;
-    const int c0 = blockIdx.y * 32;
+    constexpr int SLOTS = 256 / CQ;  // pixel slots of a block
+    const int c0 = blockIdx.y * (4 * CQ);
     const int tid = threadIdx.x;
-    const int cq = (tid & 7) * 4;
-    const int slot = tid >> 3;
+    const int cq = (tid & (CQ - 1)) * 4;
+    const int slot = tid / CQ;
     const int S = gridDim.z;
-    const int HW = HWtotal / S;  // <= 32 * NP
+    const int HW = HWtotal / S;  // <= SLOTS * NP
     // input pixel p of image b sits at x[b * img_stride + p * pix_stride + c] (a plain NHWC tensor: HWtotal*C and C)
     const float* base = x + (size_t)b * img_stride + (size_t)blockIdx.z * HW * pix_stride + c0 + cq;
+    // ct_W != 0: the slabs are those of a kernel-2 stride-2 transposed convolution run as a GEMM on the ct_W-wide coarse
+    // map (row = coarse pixel, column = (dy, dx, channel)); fine pixel (Y, X) is column block (Y & 1, X & 1) of row (Y/2, X/2)
+    auto pix_off = [&](int p) -> size_t {
+        if (ct_W == 0) return (size_t)p * pix_stride;
+        const int W2 = 2 * ct_W, Y = p / W2, X = p - Y * W2;
+        return ((size_t)(Y >> 1) * ct_W + (X >> 1)) * (4 * (size_t)C) + (size_t)(((Y & 1) << 1) | (X & 1)) * C;
+    };
     float4 v[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(base + (size_t)min(slot + 32 * i, HW - 1) * pix_stride);
+    for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(base + pix_off(min(slot + SLOTS * i, HW - 1)));
     if (n_slabs > 1) {  // x = the split-K slabs of the producing GEMM: sum them in slab order, then the bias
         for (int z = 1; z < n_slabs; ++z) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const float4 o = *reinterpret_cast<const float4*>(base + (size_t)z * slab_stride +
-                                                                  (size_t)min(slot + 32 * i, HW - 1) * pix_stride);
+                                                                  pix_off(min(slot + SLOTS * i, HW - 1)));
                 v[i].x += o.x; v[i].y += o.y; v[i].z += o.z; v[i].w += o.w;
             }
         }
@@ -264,21 +277,21 @@ __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, f
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const float m = (slot + 32 * i < HW) ? 1.f : 0.f;
+        const float m = (slot + SLOTS * i < HW) ? 1.f : 0.f;
         s.x += m * v[i].x; s.y += m * v[i].y; s.z += m * v[i].z; s.w += m * v[i].w;
     }
-    float4 mu = block_sum_by_quad(s, red, tid);
+    float4 mu = block_sum_by_quad<CQ>(s, red, tid);
     const float inv = 1.0f / (float)HW;
     mu.x *= inv; mu.y *= inv; mu.z *= inv; mu.w *= inv;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const float m = (slot + 32 * i < HW) ? 1.f : 0.f;
+        const float m = (slot + SLOTS * i < HW) ? 1.f : 0.f;
         const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
         q.x += m * dx * dx; q.y += m * dy * dy; q.z += m * dz * dz; q.w += m * dw * dw;
     }
-    const float4 var = block_sum_by_quad(q, red, tid);
-    if (tid < 8) {
+    const float4 var = block_sum_by_quad<CQ>(q, red, tid);
+    if (tid < CQ) {
         if (S > 1) {
             float* dst = part + (((size_t)b * S + blockIdx.z) * 2) * C + c0 + cq;
             *reinterpret_cast<float4*>(dst) = mu;
@@ -305,17 +318,17 @@ __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, f
         if (skip) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
-                sk[i] = *reinterpret_cast<const float4*>(skip + base_off + (size_t)min(slot + 32 * i, HW - 1) * C);
+                sk[i] = *reinterpret_cast<const float4*>(skip + base_off + (size_t)min(slot + SLOTS * i, HW - 1) * C);
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (slot + 32 * i >= HW) continue;
+            if (slot + SLOTS * i >= HW) continue;
             // same operation order as k_in_apply: normalise, + skip, + time bias
             float4 o;
             o.x = (v[i].x - mu.x) * r.x; o.y = (v[i].y - mu.y) * r.y; o.z = (v[i].z - mu.z) * r.z; o.w = (v[i].w - mu.w) * r.w;
             if (skip) { o.x += sk[i].x; o.y += sk[i].y; o.z += sk[i].z; o.w += sk[i].w; }
             o.x += add.x; o.y += add.y; o.z += add.z; o.w += add.w;
-            *reinterpret_cast<float4*>(out + base_off + (size_t)(slot + 32 * i) * C) = o;
+            *reinterpret_cast<float4*>(out + base_off + (size_t)(slot + SLOTS * i) * C) = o;
         }
     }
 }
@@ -423,16 +436,23 @@ hipError_t launch_in_stats(const float* x, float* mean, float* rstd, float* part
     if (S > 1 && (!part || (size_t)B * S * 2 * C > part_floats)) return hipErrorInvalidValue;
     if (slabs && (S > 1 || slabs->count < 2)) return hipErrorInvalidValue;
     const int per = (HW / S + 31) / 32;
-    const dim3 grid(B, C / 32, S);
+    // 16-channel blocks for the large maps while 32-channel blocks would leave CUs without one
+    const bool narrow = per > 8 && (long)B * (C / 32) * S < 256 && C % 16 == 0;
+    const dim3 grid(B, narrow ? C / 16 : C / 32, S);
     const int n_slabs = slabs ? slabs->count : 1;
     const size_t slab_stride = slabs ? slabs->stride : 0;
     const float* slab_bias = slabs ? slabs->bias : nullptr;
     const bool pm = slabs && slabs->pix_major;
+    const int ct_W = slabs ? slabs->ct_W : 0;
+    if (ct_W && (pm || !out || HW % (4 * ct_W))) return hipErrorInvalidValue;  // (the slabs are the only copy: `out` must take the sum)
     const size_t img_stride = pm ? (size_t)C : (size_t)HW * C, pix_stride = pm ? (size_t)B * C : (size_t)C;
 #define DANRA_IN_STATS(NP_)                                                                                            \
     hipLaunchKernelGGL(k_in_stats<NP_>, grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias, tb_stride, \
-                       n_slabs, slab_stride, slab_bias, img_stride, pix_stride)
-    if (per <= 2) DANRA_IN_STATS(2);
+                       n_slabs, slab_stride, slab_bias, img_stride, pix_stride, ct_W)
+    if (narrow)
+        hipLaunchKernelGGL((k_in_stats<16, 4>), grid, dim3(256), 0, stream, x, mean, rstd, part, HW, C, out, skip, tbias,
+                           tb_stride, n_slabs, slab_stride, slab_bias, img_stride, pix_stride, ct_W);
+    else if (per <= 2) DANRA_IN_STATS(2);
     else if (per <= 8) DANRA_IN_STATS(8);
     else DANRA_IN_STATS(32);
 #undef DANRA_IN_STATS
@@ -974,10 +994,14 @@ __device__ __forceinline__ float scale_one(float z, float s) {
     return z * s;
 }
 
+// With `g.table` set the kernel also gathers the time projections of the NEXT evaluation (timestep t - 1, what
+// k_tbias_gather does at the head of a step), which takes a kernel off every denoise step.  It then reads and writes
+// t_upd itself, so the hand-over is left to the block that finishes last (a ticket counter): every block has read
+// t_upd before it draws its ticket.
 __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x, const float* __restrict__ eps,
                                                            const float* __restrict__ eps_uncond,
                                                            const float4* __restrict__ coef, SampleState* state,
-                                                           size_t n4) {
+                                                           size_t n4, const NextGather g) {
     const int t = state->t_upd;
     const float4 c = coef[t];
     const float guide = state->cfg_scale, zs = state->noise_scale;
@@ -986,6 +1010,16 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
     const unsigned long long seed = state->seed, quad0 = state->quad_offset;
     const float* noise = (noisy && !state->philox && state->noise) ? state->noise + (size_t)(state->t_max - t) * (n4 * 4)
                                                                   : nullptr;
+    // the next step's first gathered element of this thread: its two dependent loads are issued ahead of the update
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    const int w4 = g.width / 4;
+    const bool gathers = g.table && t > 1;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gathers && gtid < g.B * w4) {
+        const int b = gtid / w4, j = gtid - b * w4;
+        const int c = g.y ? (int)min(max(g.y[b], (int64_t)0), (int64_t)(g.classes - 1)) : 0;
+        g0 = reinterpret_cast<const float4*>(g.table + ((size_t)(t - 1) * g.classes + c) * g.width)[j];
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 xv = reinterpret_cast<float4*>(x)[i];
         float4 ev = reinterpret_cast<const float4*>(eps)[i];
@@ -1012,16 +1046,39 @@ __global__ __launch_bounds__(256) void k_ddpm_update_state(float* __restrict__ x
         xv.w = ddpm_one(xv.w, ev.w, z.w, c.x, c.y, c.z);
         reinterpret_cast<float4*>(x)[i] = xv;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) state->t_fwd = t - 1;
+    if (!g.table) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) state->t_fwd = t - 1;
+        return;
+    }
+    if (gathers) {
+        if (gtid < g.B * w4) reinterpret_cast<float4*>(g.tbias)[gtid] = g0;
+        for (int i = gtid + gstride; i < g.B * w4; i += gstride) {
+            const int b = i / w4, j = i - b * w4;
+            const int c = g.y ? (int)min(max(g.y[b], (int64_t)0), (int64_t)(g.classes - 1)) : 0;
+            reinterpret_cast<float4*>(g.tbias)[i] =
+                reinterpret_cast<const float4*>(g.table + ((size_t)(t - 1) * g.classes + c) * g.width)[j];
+        }
+    }
+    __syncthreads();  // every wave of this block has read t_upd (and stored its rows) before the block draws its ticket
+    if (threadIdx.x == 0 && atomicAdd(&state->ticket, 1u) == gridDim.x - 1) {
+        state->ticket = 0;
+        state->t_upd = t - 1;
+        state->t_fwd = t - 1;
+    }
 }
 
 hipError_t launch_ddpm_update_state(float* x, const float* eps, const float* eps_uncond, const float4* coef,
-                                    SampleState* state, size_t n, hipStream_t stream) {
+                                    SampleState* state, size_t n, hipStream_t stream, const NextGather* next) {
     if (n % 4) return hipErrorInvalidValue;
     const size_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_ddpm_update_state, dim3(blocks), dim3(256), 0, stream, x, eps, eps_uncond, coef, state, n4);
+    NextGather g{nullptr, nullptr, nullptr, 1, 0, 0};
+    if (next) {
+        if (!next->table || !next->tbias || next->width % 4 || next->classes < 1) return hipErrorInvalidValue;
+        g = *next;
+    }
+    hipLaunchKernelGGL(k_ddpm_update_state, dim3(blocks), dim3(256), 0, stream, x, eps, eps_uncond, coef, state, n4, g);
     return hipGetLastError();
 }
 
@@ -1092,6 +1149,7 @@ __global__ void k_init_state(SampleState* s, int t_start, int philox, unsigned l
         s->cfg_scale = cfg_scale;
         s->noise_scale = noise_scale;
         s->quad_offset = quad_offset;
+        s->ticket = 0;
     }
 }
 hipError_t launch_init_state(SampleState* s, int t_start, int philox, unsigned long long seed, const float* noise,

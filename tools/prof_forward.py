@@ -15,6 +15,8 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # first kernel of a UNet evaluation: the per-step gather inside the sampler, else the time-projection kernel
     marks = [i for i, r in enumerate(rows) if "k_tbias_gather" in r["Kernel_Name"]]
+    if len(marks) < 2:  # the sampler's update kernel gathers for the next step: a step starts behind an update kernel
+        marks = [i + 1 for i, r in enumerate(rows) if "k_ddpm_update_state" in r["Kernel_Name"] and i + 1 < len(rows)]
     if len(marks) < 2:
         marks = [i for i, r in enumerate(rows) if "k_time_mlp" in r["Kernel_Name"]]
     a, b = marks[-2], marks[-1]
