@@ -70,6 +70,7 @@ struct AttnP {
     // feed-forward block of the clean-application network (src/unet.py:91-96): LayerNorm folded into the first Linear
     float *w_ff1 = nullptr, *b_ff1 = nullptr, *w_ff2 = nullptr, *b_ff2 = nullptr;
     SplitW s_in, s_out, s_ff1, s_ff2;
+    float* w_in_frag = nullptr;  // s_in in fragment order for the fused short-sequence kernel (launch_split_to_frag16), or null
     int C = 0;
 };
 struct BlockP {
@@ -130,6 +131,8 @@ struct danra_handle_s {
     AttnP attn[9];
     DecP dec[4];
     float *final_wt = nullptr, *final_bt = nullptr;
+    // DANRA_FUSED_SMALL_ATTENTION=0 keeps the three-kernel form of the short-sequence attention blocks (comparison runs)
+    bool fused_small_attention = !(getenv("DANRA_FUSED_SMALL_ATTENTION") && atoi(getenv("DANRA_FUSED_SMALL_ATTENTION")) == 0);
     SplitW final_s_wt;
     float *tw = nullptr, *tb = nullptr;  // time projections [tb_width][dim], [tb_width]
     float* label_emb = nullptr;
@@ -305,6 +308,8 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         a.b_out = bp.take(C);
         want_split(a.s_in, a.w_in, (size_t)3 * C, C, true);
         want_split(a.s_out, a.w_out, C, C, true);
+        // (filled behind split_registered; the shapes attn_block_small_supported knows)
+        a.w_in_frag = (h->cfg.n_heads == 4 && (C == 128 || C == 256 || C == 512)) ? bh.take((size_t)3 * C * C) : nullptr;
         if (h->cfg.attn_ff) {
             a.w_ff1 = bp.take((size_t)C * C);
             a.b_ff1 = bp.take(C);
@@ -726,27 +731,33 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     const AttnP& at = h->attn[index];
     const int C = at.C, heads = h->cfg.n_heads, hd = C / heads;
     Workspace& ws = h->ws;
-    IGemmArgs a = blank_args();
-    a.A = x; a.lda = C; a.ln = 1; a.a_mode = A_GEMM;
-    a.W = at.w_in; a.bias = at.b_in; a.out = ws.qkv;
-    use_split(a, at.s_in);
-    a.M = B * L; a.N = 3 * C; a.K = C;
-    a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
-    a.qkv_plane = (long long)B * L * C;
-    choose_split(a, ws);
-    RC_TRY(igemm(h, a, st));
-    const size_t plane = (size_t)B * L * C;
-    const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
-    const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
-    {
-        ProfScope scope(h, timed);
-        HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
-    }
-    if (timed) {
-        const double fl = 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
-        h->prof_flops += fl;
-        h->prof_exec_flops += (hd == 16 && L % 128 == 0) ? 3.5 * fl : fl;  // head_dim 16: 4 + 3 fp16 instructions per 2 algorithmic products
-        h->prof_bytes += 4.0 * 4.0 * (double)plane;  // q, k, v read once, the head outputs written once
+    if (attn_block_small_supported(B, L, C, heads) && h->fused_small_attention && at.w_in_frag && !igemm_fp32_products_forced()) {
+        // short sequences of the deep levels: LayerNorm, QKV projection and attention as one kernel per (image, head)
+        // (a split-operand product; with fp32 products forced the three-kernel form below runs)
+        HIP_TRY(launch_attn_block_small(x, at.w_in_frag, at.s_in.inv_scale, at.b_in, ws.obuf, B, L, C, heads, st));
+    } else {
+        IGemmArgs a = blank_args();
+        a.A = x; a.lda = C; a.ln = 1; a.a_mode = A_GEMM;
+        a.W = at.w_in; a.bias = at.b_in; a.out = ws.qkv;
+        use_split(a, at.s_in);
+        a.M = B * L; a.N = 3 * C; a.K = C;
+        a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
+        a.qkv_plane = (long long)B * L * C;
+        choose_split(a, ws);
+        RC_TRY(igemm(h, a, st));
+        const size_t plane = (size_t)B * L * C;
+        const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
+        const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
+        {
+            ProfScope scope(h, timed);
+            HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+        }
+        if (timed) {
+            const double fl = 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
+            h->prof_flops += fl;
+            h->prof_exec_flops += (hd == 16 && L % 128 == 0) ? 3.5 * fl : fl;  // head_dim 16: 4 + 3 fp16 instructions per 2 algorithmic products
+            h->prof_bytes += 4.0 * 4.0 * (double)plane;  // q, k, v read once, the head outputs written once
+        }
     }
     // With the feed-forward block the attended tokens a = out_proj(o) + x go to the (now idle) q/k/v buffer,
     // h = GELU(Linear1(LayerNorm(a))) to the (now idle) head-output buffer, and out = act(a + Linear2(h)).
@@ -1103,6 +1114,11 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
     RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
     for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
+    for (AttnP& at : h->attn) {
+        if (!at.w_in_frag) continue;
+        if (!at.s_in.wh) { at.w_in_frag = nullptr; continue; }  // (an all-zero or non-finite matrix keeps the fp32 form)
+        HIP_TRY(launch_split_to_frag16(at.s_in.wh, at.w_in_frag, 3 * at.C, at.C, st));
+    }
     h->freq_dirty = true;
     RC_TRY(upload_freq(h, st));
     for (ParamEntry& p : h->params) p.src = nullptr;  // borrowed pointers are not kept

@@ -113,6 +113,18 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads,
                             int L, int hd, hipStream_t stream);
+// LayerNorm + QKV projection of one head + that head's attention as one kernel per (image, head), for the short
+// sequences of the deep levels (see attn_block_small_supported): x [B][L][C] tokens, w_in_frag = in_proj [3C][C] with
+// the LayerNorm affine folded in, split in fp16 halves after a scale of 1 / wscale (launch_split_weights) and brought
+// into fragment order (launch_split_to_frag16), b_in [3C], o [B][L][C] head outputs (the operand of the output
+// projection).
+bool attn_block_small_supported(int B, int L, int C, int heads);
+hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float wscale, const float* b_in, float* o,
+                                   int B, int L, int C, int heads, hipStream_t stream);
+// split [rows][K] (launch_split_weights without frag64; rows % 16 == 0, K % 64 == 0) -> out, same size: for 16-row tile T
+// and 32-deep step s the 64 x 16 bytes of lanes (row 16 T + (lane & 15), k = 32 s + 8 (lane >> 4) ..) hi, then lo.
+hipError_t launch_split_to_frag16(const float* split, float* out, int rows, int K, hipStream_t stream);
+bool igemm_fp32_products_forced();
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,

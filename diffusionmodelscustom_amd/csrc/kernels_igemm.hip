@@ -40,6 +40,7 @@ static constexpr int BN = 64;
 // process-wide switch: every product of this file with fp32 matrix instructions (danra_set_fp32_products)
 static int g_igemm_fp32_products = 0;
 void set_igemm_fp32_products(int on) { g_igemm_fp32_products = on ? 1 : 0; }
+bool igemm_fp32_products_forced() { return g_igemm_fp32_products != 0; }
 
 // x / d for x >= 0, d > 0: a shift when the host found d to be a power of two (sh = its log2, else -1).  Every
 // feature map of the networks this library runs has power-of-two sides; an integer division by a run-time value

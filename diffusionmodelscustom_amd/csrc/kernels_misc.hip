@@ -1278,6 +1278,30 @@ hipError_t launch_split_weights(const float* w, float* out, size_t n, float scal
     return hipGetLastError();
 }
 
+// The k_igemm split layout -> fragment order of the 16x16x32 matrix instruction (see launch_split_to_frag16).
+__global__ __launch_bounds__(256) void k_split_to_frag16(const _Float16* __restrict__ wh, _Float16* __restrict__ out,
+                                                         int rows, int K) {
+    const int g8 = K / 8, KS = K / 32;
+    const size_t total = (size_t)rows * g8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g8), k0 = (int)(idx - (size_t)n * g8) * 8;
+        const size_t i = (size_t)n * K + k0;
+        const _Float16* src = wh + (i >> 6) * 128 + (i & 63);
+        const int T = n >> 4, c = n & 15, s2 = k0 >> 5, kg = (k0 & 31) >> 3;
+        _Float16* dst = out + ((size_t)T * KS + s2) * 1024 + (kg * 16 + c) * 8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        *reinterpret_cast<uint4*>(dst + 512) = *reinterpret_cast<const uint4*>(src + 64);
+    }
+}
+hipError_t launch_split_to_frag16(const float* split, float* out, int rows, int K, hipStream_t stream) {
+    if (rows % 16 || K % 64) return hipErrorInvalidValue;
+    int blocks = (int)(((size_t)rows * (K / 8) + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_split_to_frag16, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(split),
+                       reinterpret_cast<_Float16*>(out), rows, K);
+    return hipGetLastError();
+}
+
 __global__ void k_pack_convT(const float* w, const float* bias, float* wout, float* bout, int Ci, int Co) {
     // w [Ci][Co][2][2] -> wout [(dy*2+dx)*Co + co][ci]; bout = bias tiled over the four sub-pixels
     const size_t total = (size_t)4 * Co * Ci;

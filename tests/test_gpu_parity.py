@@ -84,6 +84,34 @@ def test_attention_batch_and_relu(cond64, dev):
     assert rel_err(ops.attention(2, x.to(dev)).cpu(), want) < TOL_OP
 
 
+@pytest.mark.parametrize("index,prefix,C,side,batch", [
+    (2, "encoder.attention_layers.2", 128, 8, 5),                 # 64 tokens: one workgroup per (image, head)
+    (6, "decoder.residual_layers.1.attention", 128, 8, 3),
+    (3, "encoder.attention_layers.3", 256, 4, 6),                 # 16 tokens
+    (5, "decoder.residual_layers.0.attention", 256, 4, 2),
+    (4, "encoder.attention_layers.4", 512, 2, 8),                 # 4 tokens: four images per workgroup, masked scores
+    (4, "encoder.attention_layers.4", 512, 2, 4),
+    (4, "encoder.attention_layers.4", 512, 2, 6),                 # batch not a multiple of 4: the three-kernel form
+])
+def test_short_sequence_attention_blocks(cond64, dev, index, prefix, C, side, batch):
+    """LayerNorm + QKV projection + attention of the deep levels as one kernel per (image, head) (k_attn_block_small),
+    at batches > 1, against the restatement; images must not see each other where a workgroup holds four of them."""
+    _, sd, ops = cond64
+    x = gs.randn(300 + index + batch, batch, C, side, side)
+    x[0, :, 0, 0] = 0.25          # a token whose channels are all equal: LayerNorm maps it to zero
+    if batch > 1:
+        x[1] *= 30.0              # images of very different scale side by side
+    relu = index >= 5
+    want = cpu_ref.image_self_attention(sd, prefix, x)
+    if relu:
+        want = torch.relu(want)
+    got = ops.attention(index, x.to(dev), relu=relu).cpu()
+    assert rel_err(got, want) < TOL_OP
+    # per image: the error bar above is relative to the whole tensor, the small-scale images must hold it on their own
+    for b in range(batch):
+        assert rel_err(got[b], want[b]) < 2 * TOL_OP, f"image {b}"
+
+
 def test_attention_softmax_is_stable_for_large_logits(cond64, dev):
     """Scores far beyond exp()'s fp32 range must not overflow: the running maximum is subtracted."""
     _, sd, ops = cond64

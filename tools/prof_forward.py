@@ -4,6 +4,7 @@
     python tools/prof_forward.py gpurun_out/prof_r1/r1_kernel_trace.csv [--brief]
 """
 import csv
+import re
 import sys
 from collections import defaultdict
 
@@ -26,6 +27,10 @@ def main():
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000
         tot += d
         name = r["Kernel_Name"].split("(")[0].replace("danra::", "").replace("void ", "")
+        if name.startswith("_ZN5danra"):  # a name the profiler's demangler gave up on (an _Float16 parameter)
+            m = re.match(r"_ZN5danra\d+([a-z_0-9]+?)I((?:Li\d+E)*)E", name)
+            if m:
+                name = m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
         per[name][0] += 1
         per[name][1] += d
         if not brief:
