@@ -880,15 +880,16 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
     Workspace& ws = h->ws;
     const DecP& d = h->dec[k];
     const int H2 = 2 * Hh, W2 = 2 * Ww;
-    // The first InstanceNorm: while an image's pixels fit the registers of the block that forms its statistics, that
-    // block also writes the normalised values back (in place) and the convolution reads a plain tensor.  Normalising
-    // in the convolution's operand loader instead costs it two more 16-byte loads (mean, 1/std) per activation load,
-    // and the loader is what its loop waits for: 19-21 us against 11 us per launch at 64 images.
+    // The first InstanceNorm of the small maps: the block that forms an image's statistics holds its pixels in
+    // registers, so it also writes the normalised values back (in place) and the convolution reads a plain tensor.
+    // Normalising in the convolution's operand loader instead costs it two more 16-byte loads (mean, 1/std) per
+    // activation load, and the loader is what its loop waits for: 21 against 16 us per launch at 64 images on a 4x4 map.
     bool normalised = false;
     if (!up_ready) {
         InSlabs up_slabs{0, 0, nullptr, 0, 0};
-        static const int in_place_px = getenv("DANRA_IN_PLACE_PX") ? atoi(getenv("DANRA_IN_PLACE_PX")) : 64;
-        normalised = H2 * W2 <= in_place_px && H2 * W2 <= 1024;
+        // (measured at 64 images: pays up to 8x8 maps; from 16x16 on the extra store costs the statistics kernel what
+        // the convolution gains, 2 us each, and at 32x32 more: +6 against -3.4 us)
+        normalised = H2 * W2 <= 64;
         // (... and when the transposed convolution is split over K, that block sums its slabs as well)
         RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt, normalised ? &up_slabs : nullptr));
         HIP_TRY(launch_in_stats(up_slabs.count ? ws.partial : ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats,

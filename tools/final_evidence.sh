@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): everything profiles/ keeps for one library build, in one call - the full GPU test
+# log, the bench lines of every workload with the kernel summary and timeline of the default one, the 2-rank
+# rehearsal line, and the counter passes.  Results land under gpurun_out/final/ (and gpurun_out/refresh, pmc, pmc_sq).
+set -eo pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/final
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -v --timeout 180 --timeout-method thread > "$OUT/gpu_tests_full.txt" 2>&1
+tail -1 "$OUT/gpu_tests_full.txt"
+bash tools/refresh_profiles.sh > "$OUT/refresh.log" 2>&1
+for w in clean clean_cfg clean_h1; do
+    timeout -k 10 400 python3 bench.py --workload $w > "$OUT/bench_$w.log" 2>&1
+    grep -o '{"metric.*' "$OUT/bench_$w.log" > "$OUT/bench_$w.json"
+done
+DANRA_BENCH_REHEARSAL=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --timesteps 200 --no-cpu-baseline > "$OUT/rehearsal.log" 2>&1
+grep -o '{"metric.*' "$OUT/rehearsal.log" > "$OUT/bench_rehearsal_2rank.json"
+bash tools/pmc_traffic.sh > "$OUT/pmc_traffic.log" 2>&1
+bash tools/pmc_sq.sh > "$OUT/pmc_sq.log" 2>&1
+echo done
