@@ -223,7 +223,9 @@ def test_training_step_gradients(builder, monkeypatch):
     evaluation of the same step on the CPU, for three float32 evaluations on the GPU: the 64-channel attention cores in
     the native library with their default split-operand fp16 products, the same kernels with fp32 matrix instructions
     only, and torch's own attention core.  Bars, per evaluation: the median over the parameter tensors of the rms gradient
-    error (relative to the tensor's rms) at most 2e-4 (1e-3 for the evaluation with torch's core), and no tensor further than 3e-2.
+    error (relative to the tensor's rms) at most 1e-3, and no tensor further than 3e-2.  What the kernels themselves
+    keep is pinned elsewhere, free of kinks: every native kernel of the step has its own test against float64 at 1e-5
+    (the attention core's forward and backward among them, on the value ranges of the split-operand form).
 
     Why eight images: the gradient of this piecewise-linear network is discontinuous wherever a ReLU input crosses
     zero, and of its few million ReLU inputs a handful always sit within float32 rounding of zero, so two correct float32
@@ -233,9 +235,13 @@ def test_training_step_gradients(builder, monkeypatch):
     other network - while evaluations on the same side agree to 5e-6.  A flip's share of a mean-squared-error gradient
     falls with the number of images; at eight one flip moves the tensors next to it by 1e-3 to 6e-3 (every one of the
     three GPU evaluations has met one in some run, torch's own included) and leaves most tensors where they were, while
-    an evaluation that meets no flip agrees with float64 to 2e-6 in every tensor.  Hence the two bars: the median, which
-    a flip does not move and a loss of precision in a kernel would (operands rounded to plain fp16 are off by up to
-    5e-4 each), and a ceiling per tensor that a few flips stay under and a wrong kernel does not."""
+    an evaluation that meets no flip agrees with float64 to 2e-6 in every tensor.  A flip late in the network is felt by
+    every layer upstream of it: in one run the split-operand evaluation and torch's core both sat at a median of 2.0e-4 /
+    1.8e-4 (worst tensor encoder.conv2.weight, 3.3e-3 / 2.9e-3) while the fp32-instruction evaluation of the same library,
+    on the other side of that kink, agreed with float64 to 2.0e-7 in the median and 1.9e-6 in the worst tensor; in other
+    runs of the same build all three agreed to 2e-6.  Which side an evaluation lands on changes from run to run (the
+    step contains torch kernels that accumulate in no fixed order).  Hence bars that a few flips stay under and a wrong
+    kernel or a mis-wired gradient does not: 1e-3 on the median, 3e-2 on any tensor."""
     torch.manual_seed(11)
     model = builder()
     model.train()
@@ -288,10 +294,7 @@ def test_training_step_gradients(builder, monkeypatch):
     print(text)
     for name, (loss_err, err, tensor, median) in report.items():
         assert loss_err <= 2e-6, f"{name}: loss off by {loss_err:.2e} relative to float64 [{text}]"
-        # (torch's fused scaled-dot-product attention is the less exact of the three cores: with it a flip in the second
-        # layer has been seen to carry 2.0e-4 into most tensors; it is here for comparison, its bar is 1e-3)
-        bar = 1e-3 if name.startswith("torch") else 2e-4
-        assert median <= bar, f"{name}: median gradient error {median:.3e} of the tensors' rms [{text}]"
+        assert median <= 1e-3, f"{name}: median gradient error {median:.3e} of the tensors' rms [{text}]"
         assert err <= 3e-2, f"{name}: gradient of {tensor} is {err:.3e} of its rms away from float64 [{text}]"
 
 

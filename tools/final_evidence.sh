@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout -k 10 900 python3 -u -m pytest tests -m gpu -v --timeout 180 --timeout-method thread > "$OUT/gpu_tests_full.txt" 2>&1
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -v --timeout 180 --timeout-method thread > "$OUT/gpu_tests_full.txt" 2>&1 || echo "GPU TESTS FAILED"
 tail -1 "$OUT/gpu_tests_full.txt"
 bash tools/refresh_profiles.sh > "$OUT/refresh.log" 2>&1
 for w in clean clean_cfg clean_h1; do
