@@ -465,6 +465,48 @@ def test_split_operand_convolution_value_ranges(cond64, dev, case):
             assert float((g - w).abs().max()) <= TOL_OP * scale, (case, b, rows)
 
 
+def test_fused_attention_blocks_equal_the_separate_kernels(cond64, dev, monkeypatch):
+    """A whole forward at the benchmark's batch (64 images: every fused short-sequence attention kernel runs, the 2x2
+    level with four images per workgroup) against a second engine created with DANRA_FUSED_SMALL_ATTENTION=0, whose
+    blocks run the LayerNorm-fused QKV GEMM and the attention kernel separately."""
+    model, _, _ = cond64
+    B = 64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64).items()}
+    t = torch.randint(1, 1000, (B,), generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        fused = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
+    monkeypatch.setenv("DANRA_FUSED_SMALL_ATTENTION", "0")
+    other = build_model("cond", 64).to(dev)  # the same seeded weights; its engine is created under the switch
+    with torch.no_grad():
+        separate = other(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
+    assert rel_err(fused, separate) < 2e-5
+    assert not torch.equal(fused, separate), "the switch changed nothing: one of the two forms did not run"
+    for b in range(B):  # no image may be off on its own (a workgroup of the 2x2 level holds four of them)
+        assert rel_err(fused[b], separate[b]) < 1e-4, f"image {b}"
+
+
+@pytest.mark.parametrize("T", [2, 3, 4])
+def test_shortest_sampling_chains(cond64, dev, T):
+    """T = 2 is one evaluation and a noise-free update, T = 3 the first chain in which the update kernel hands a gathered
+    set of time projections to a following evaluation; against the restatement with the same draws."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, sd, _ = cond64
+    B = 3
+    cpu_in = gs.variant_inputs("cond", B, 64)
+    noise = torch.randn(max(T - 2, 0), B, 1, 64, 64, generator=torch.Generator().manual_seed(T))
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+    inp = {k: v.to(dev) for k, v in cpu_in.items()}
+    got = du.sample_with_host_noise(inp["x"], model, noise.to(dev), inp["y"], cond_img=inp["cond_img"],
+                                    lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"])
+    draws = iter(noise)
+    want = cpu_ref.sample(sd, cpu_in["x"], T, gs.BETA_MIN, gs.BETA_MAX, cpu_in["y"], cpu_in["cond_img"], cpu_in["lsm_cond"],
+                          cpu_in["topo_cond"], noise_fn=lambda i, x: next(draws))
+    assert rel_err(got.cpu(), want) < TOL_FWD
+    again = du.sample_with_host_noise(inp["x"], model, noise.to(dev), inp["y"], cond_img=inp["cond_img"],
+                                      lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"])
+    assert torch.equal(got, again)  # the loop state (timestep, ticket of the update kernel) starts afresh in every call
+
+
 def test_split_operand_forward_equals_fp32_products(cond64, golden, dev):
     """danra_set_fp32_products(1) runs every product of the network with fp32 matrix instructions; both forms meet the
     forward tolerance against the reference's own output and agree with each other far inside it."""
