@@ -71,6 +71,7 @@ struct AttnP {
     float *w_ff1 = nullptr, *b_ff1 = nullptr, *w_ff2 = nullptr, *b_ff2 = nullptr;
     SplitW s_in, s_out, s_ff1, s_ff2;
     float* w_in_frag = nullptr;  // s_in in fragment order for the fused short-sequence kernel (launch_split_to_frag16), or null
+    float* w_out_frag = nullptr; // s_out in fragment order for k_proj_small, or null
     int C = 0;
 };
 struct BlockP {
@@ -310,6 +311,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         want_split(a.s_out, a.w_out, C, C, true);
         // (filled behind split_registered; the shapes attn_block_small_supported knows)
         a.w_in_frag = (h->cfg.n_heads == 4 && (C == 128 || C == 256 || C == 512)) ? bh.take((size_t)3 * C * C) : nullptr;
+        a.w_out_frag = (C == 128 || C == 256 || C == 512) ? bh.take((size_t)C * C) : nullptr;
         if (h->cfg.attn_ff) {
             a.w_ff1 = bp.take((size_t)C * C);
             a.b_ff1 = bp.take(C);
@@ -776,6 +778,12 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         return DANRA_OK;
     }
     float* attended = ff ? ws.qkv : out;
+    if (at.w_out_frag && h->fused_small_attention && !igemm_fp32_products_forced() && proj_small_supported(B * L, C, C)) {
+        // few rows: the whole product as one trip to memory per wave instead of a tiled GEMM (+ split-K reduction)
+        HIP_TRY(launch_proj_small(ws.obuf, at.w_out_frag, at.w_out, at.s_out.inv_scale, at.b_out, x, attended, B * L, C, C,
+                                  (relu && !ff) ? 1 : 0, st));
+        if (!ff) return DANRA_OK;
+    } else {
     IGemmArgs o = blank_args();
     o.A = ws.obuf; o.lda = C; o.a_mode = A_GEMM;
     use_split(o, at.s_out);
@@ -784,6 +792,7 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     choose_split(o, ws);
     RC_TRY(igemm(h, o, st));
     if (!ff) return DANRA_OK;
+    }
     IGemmArgs f1 = blank_args();
     f1.A = attended; f1.lda = C; f1.ln = 1; f1.a_mode = A_GEMM;
     use_split(f1, at.s_ff1);
@@ -1116,10 +1125,11 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
     RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
     for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
-    for (AttnP& at : h->attn) {
-        if (!at.w_in_frag) continue;
-        if (!at.s_in.wh) { at.w_in_frag = nullptr; continue; }  // (an all-zero or non-finite matrix keeps the fp32 form)
-        HIP_TRY(launch_split_to_frag16(at.s_in.wh, at.w_in_frag, 3 * at.C, at.C, st));
+    for (AttnP& at : h->attn) {  // (an all-zero or non-finite matrix has no split copy and keeps the fp32 form)
+        if (at.w_in_frag && !at.s_in.wh) at.w_in_frag = nullptr;
+        if (at.w_out_frag && !at.s_out.wh) at.w_out_frag = nullptr;
+        if (at.w_in_frag) HIP_TRY(launch_split_to_frag16(at.s_in.wh, at.w_in_frag, 3 * at.C, at.C, st));
+        if (at.w_out_frag) HIP_TRY(launch_split_to_frag16(at.s_out.wh, at.w_out_frag, at.C, at.C, st));
     }
     h->freq_dirty = true;
     RC_TRY(upload_freq(h, st));

@@ -125,6 +125,12 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
 // and 32-deep step s the 64 x 16 bytes of lanes (row 16 T + (lane & 15), k = 32 s + 8 (lane >> 4) ..) hi, then lo.
 hipError_t launch_split_to_frag16(const float* split, float* out, int rows, int K, hipStream_t stream);
 bool igemm_fp32_products_forced();
+// out = act(A W^T + bias + res) for products with few rows (K = 128 / 256 / 512, M <= 8192; see proj_small_supported):
+// the output projections of the short-sequence attention blocks.  w_frag = W split in fp16 halves in fragment order
+// (scale 1 / wscale), w = the fp32 matrix (for rows outside the split's range).
+bool proj_small_supported(int M, int N, int K);
+hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
+                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream);
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,

@@ -1152,6 +1152,138 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Output projection of the short-sequence attention blocks: out = act(A W^T + bias + res) for a few hundred to a few
+// thousand rows and K = N = 128 / 256 / 512.  Through k_igemm such a product is two to eight chunks of work inside
+// 7-8 us of launch, pipeline fill and epilogue (plus a split-K reduction kernel at 256 rows).  Here a wave owns one
+// 16-row tile and NCT of the 16-column tiles: its weight fragments (split fp16 halves in fragment order, see
+// launch_split_to_frag16) and its rows are all in flight in one trip to memory, the rows are split in registers,
+// and the 3 * NCT * K / 32 matrix instructions run back to back; residual and bias arrive meanwhile.  No LDS, no
+// barrier, one wave per workgroup (a few hundred waves spread over all CUs: 5.6-6.2 us where k_igemm took 7.5-8.2 and,
+// with its split-K reduction at 256 rows, 11.7; four waves per workgroup on a quarter of the CUs took 9.2).  A wave whose rows leave the range of the split (a value >= 2^15 or non-finite, or nothing but values below
+// 2^-8 that are not all zero) multiplies with fp32 instructions from the fp32 matrix instead.
+//   A [M][K], Wf = W [N][K] split and in fragment order (scale 1 / wscale), W the fp32 matrix, res [M][N] or null
+// (The transposed convolutions of the small decoder maps, 1024 such waves each, are not faster this way than through
+// k_igemm - 9.2-11.0 against 8.2-10.5 us: every wave fetches its weights again.)
+template <int KS, int NCT>
+__global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, const _Float16* __restrict__ Wf,
+                                                    const float* __restrict__ W, float wscale,
+                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                    float* __restrict__ out, int M, int N, int relu) {
+    constexpr int K = 32 * KS;
+    const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int task = blockIdx.x;  // one wave per workgroup: a few hundred tasks spread over all CUs
+    const int groups = N / (16 * NCT);  // column groups per row tile
+    const int rt = task / groups, cg = task - rt * groups;
+    if (rt * 16 >= M) return;
+    const int row = min(rt * 16 + c, M - 1);  // (rows past M are computed from row M - 1 and not stored)
+    // ---- loads: the weight fragments of this wave's column tiles, then its rows
+    f16x8 wh[NCT][KS], wl[NCT][KS];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+        const _Float16* wr = Wf + (size_t)(cg * NCT + t) * (KS * 1024) + lane * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            wh[t][s2] = *reinterpret_cast<const f16x8*>(wr + s2 * 1024);
+            wl[t][s2] = *reinterpret_cast<const f16x8*>(wr + s2 * 1024 + 512);
+        }
+    }
+    float xf[8 * KS];  // xf[8 s + e] = A[row][32 s + 8 kg + e]
+    {
+        const float* ar = A + (size_t)row * K + 8 * kg;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const float4 v0 = *reinterpret_cast<const float4*>(ar + 32 * s2);
+            const float4 v1 = *reinterpret_cast<const float4*>(ar + 32 * s2 + 4);
+            xf[8 * s2] = v0.x; xf[8 * s2 + 1] = v0.y; xf[8 * s2 + 2] = v0.z; xf[8 * s2 + 3] = v0.w;
+            xf[8 * s2 + 4] = v1.x; xf[8 * s2 + 5] = v1.y; xf[8 * s2 + 6] = v1.z; xf[8 * s2 + 7] = v1.w;
+        }
+    }
+    // what the epilogue adds: lane (c, kg) ends up with columns n0 + 4 kg .. + 3 of row rt * 16 + c
+    float4 bv[NCT], rv[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+        const int n = (cg * NCT + t) * 16 + 4 * kg;
+        bv[t] = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[t] = res ? *reinterpret_cast<const float4*>(res + (size_t)row * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (keeps every load above ahead of the first use)
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8 * KS; ++k) amax = fmaxf(amax, fabsf(xf[k]));
+    const bool bad = !(amax < 32768.f) || (amax > 0.f && amax < 0.00390625f);
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float scale = wscale;
+    if (__any(bad)) {  // rare: fp32 instructions, the fp32 matrix straight from memory (k = 32 s + 8 kg + e on both sides)
+        scale = 1.0f;
+        for (int t = 0; t < NCT; ++t) {
+            const float* wr = W + (size_t)((cg * NCT + t) * 16 + c) * K + 8 * kg;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wr + 32 * s2);
+                const float4 w1 = *reinterpret_cast<const float4*>(wr + 32 * s2 + 4);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, xf[8 * s2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, xf[8 * s2 + 1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, xf[8 * s2 + 2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, xf[8 * s2 + 3], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, xf[8 * s2 + 4], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, xf[8 * s2 + 5], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, xf[8 * s2 + 6], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, xf[8 * s2 + 7], acc[t], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair_f16(xf[8 * s2 + 2 * e], xf[8 * s2 + 2 * e + 1], hi[e], lo[e]);
+            const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+            const f16x8 xl = __builtin_bit_cast(f16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][s2], xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][s2], xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][s2], xh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (rt * 16 + c >= M) return;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+        const int n = (cg * NCT + t) * 16 + 4 * kg;
+        float4 v = make_float4(acc[t][0] * scale + bv[t].x, acc[t][1] * scale + bv[t].y, acc[t][2] * scale + bv[t].z,
+                               acc[t][3] * scale + bv[t].w);
+        if (res) { v.x += rv[t].x; v.y += rv[t].y; v.z += rv[t].z; v.w += rv[t].w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(out + (size_t)row * N + n) = v;
+    }
+}
+
+// K = 128 / 256 / 512, N a multiple of what a wave takes at that K, and at most 8192 rows (beyond that k_igemm's tiles
+// are the better shape).
+bool proj_small_supported(int M, int N, int K) {
+    const int per_wave = K == 128 ? 128 : K == 256 ? 64 : K == 512 ? 32 : 0;
+    return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= 8192 && (long)M * N < (1l << 30);
+}
+
+hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
+                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream) {
+    if (!proj_small_supported(M, N, K) || !w_frag || !w) return hipErrorInvalidValue;
+    const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
+    const int rts = (M + 15) / 16;
+    // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512
+    if (K == 128)
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+    else if (K == 256)
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+    else
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+    return hipGetLastError();
+}
+
 static int g_hd16_fp32_products = 0;
 void set_attention_hd16_fp32_products(int on) { g_hd16_fp32_products = on ? 1 : 0; }
 

@@ -112,6 +112,31 @@ def test_short_sequence_attention_blocks(cond64, dev, index, prefix, C, side, ba
         assert rel_err(got[b], want[b]) < 2 * TOL_OP, f"image {b}"
 
 
+@pytest.mark.parametrize("factor", [3e5, 1e-7])
+def test_short_sequence_output_projection_outside_the_split_range(dev, factor):
+    """The output projection of the short-sequence blocks (k_proj_small) multiplies rows of attention output; value
+    projections scaled by 3e5 push those rows beyond 2^15, scaled by 1e-7 below 2^-8: both take the kernel's fp32
+    instructions and must meet the same tolerance."""
+    from gpu_util import Ops
+    model = build_model("cond", 64)
+    with torch.no_grad():
+        for prefix, C in (("encoder.attention_layers.2", 128), ("encoder.attention_layers.3", 256), ("encoder.attention_layers.4", 512)):
+            mha = model.get_submodule(prefix).attention
+            mha.in_proj_weight[2 * C:] *= factor
+            mha.in_proj_bias[2 * C:] *= factor
+    sd = state_dict_cpu(model)
+    ops = Ops(model.to(dev).hip_engine(dev))
+    for index, prefix, C, side in ((2, "encoder.attention_layers.2", 128, 8), (3, "encoder.attention_layers.3", 256, 4),
+                                   (4, "encoder.attention_layers.4", 512, 2)):
+        x = gs.randn(400 + index, 4, C, side, side)
+        want = cpu_ref.image_self_attention(sd, prefix, x)
+        got = ops.attention(index, x.to(dev)).cpu()
+        assert torch.isfinite(got).all()
+        assert rel_err(got, want) < TOL_OP, (index, factor)
+        if factor < 1:  # the residual dominates: hold the projection's own share to the tolerance as well
+            assert rel_err(got - x, want - x) < 10 * TOL_OP, (index, factor)
+
+
 def test_attention_softmax_is_stable_for_large_logits(cond64, dev):
     """Scores far beyond exp()'s fp32 range must not overflow: the running maximum is subtracted."""
     _, sd, ops = cond64
