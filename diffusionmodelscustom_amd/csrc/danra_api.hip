@@ -312,6 +312,10 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         // (filled behind split_registered; the shapes attn_block_small_supported knows)
         a.w_in_frag = (h->cfg.n_heads == 4 && (C == 128 || C == 256 || C == 512)) ? bh.take((size_t)3 * C * C) : nullptr;
         a.w_out_frag = (C == 128 || C == 256 || C == 512) ? bh.take((size_t)C * C) : nullptr;
+        if (C == 64) {  // (the K = 64 split copies are in k_gemm_k64's own order: these come from the fp32 matrices)
+            a.w_in_frag = bh.take((size_t)3 * C * C);
+            a.w_out_frag = bh.take((size_t)C * C);
+        }
         if (h->cfg.attn_ff) {
             a.w_ff1 = bp.take((size_t)C * C);
             a.b_ff1 = bp.take(C);
@@ -739,6 +743,8 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         // (a split-operand product; with fp32 products forced the three-kernel form below runs)
         HIP_TRY(launch_attn_block_small(x, at.w_in_frag, at.s_in.inv_scale, at.b_in, ws.obuf, B, L, C, heads, st));
     } else {
+        const bool lean_qkv = at.w_in_frag && h->fused_small_attention && !igemm_fp32_products_forced() &&
+                              qkv_small_supported(B * L, C, L, hd);
         IGemmArgs a = blank_args();
         a.A = x; a.lda = C; a.ln = 1; a.a_mode = A_GEMM;
         a.W = at.w_in; a.bias = at.b_in; a.out = ws.qkv;
@@ -747,7 +753,10 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
         a.qkv_plane = (long long)B * L * C;
         choose_split(a, ws);
-        RC_TRY(igemm(h, a, st));
+        if (lean_qkv)  // few tokens: one trip to memory per wave instead of a tiled GEMM
+            HIP_TRY(launch_qkv_small(x, at.w_in_frag, at.w_in, at.s_in.inv_scale, at.b_in, ws.qkv, B * L, C, L, hd, st));
+        else
+            RC_TRY(igemm(h, a, st));
         const size_t plane = (size_t)B * L * C;
         const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
         const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
@@ -1128,6 +1137,11 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     for (AttnP& at : h->attn) {  // (an all-zero or non-finite matrix has no split copy and keeps the fp32 form)
         if (at.w_in_frag && !at.s_in.wh) at.w_in_frag = nullptr;
         if (at.w_out_frag && !at.s_out.wh) at.w_out_frag = nullptr;
+        if (at.C == 64) {
+            if (at.w_in_frag) HIP_TRY(launch_frag16_from_f32(at.w_in, at.w_in_frag, 3 * at.C, at.C, 1.0f / at.s_in.inv_scale, st));
+            if (at.w_out_frag) HIP_TRY(launch_frag16_from_f32(at.w_out, at.w_out_frag, at.C, at.C, 1.0f / at.s_out.inv_scale, st));
+            continue;
+        }
         if (at.w_in_frag) HIP_TRY(launch_split_to_frag16(at.s_in.wh, at.w_in_frag, 3 * at.C, at.C, st));
         if (at.w_out_frag) HIP_TRY(launch_split_to_frag16(at.s_out.wh, at.w_out_frag, at.C, at.C, st));
     }

@@ -1165,11 +1165,12 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
 //   A [M][K], Wf = W [N][K] split and in fragment order (scale 1 / wscale), W the fp32 matrix, res [M][N] or null
 // (The transposed convolutions of the small decoder maps, 1024 such waves each, are not faster this way than through
 // k_igemm - 9.2-11.0 against 8.2-10.5 us: every wave fetches its weights again.)
-template <int KS, int NCT>
+template <int KS, int NCT, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, const _Float16* __restrict__ Wf,
                                                     const float* __restrict__ W, float wscale,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                    float* __restrict__ out, int M, int N, int relu) {
+                                                    float* __restrict__ out, int M, int N, int relu, int qkv_L,
+                                                    int qkv_hd) {
     constexpr int K = 32 * KS;
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
     const int task = blockIdx.x;  // one wave per workgroup: a few hundred tasks spread over all CUs
@@ -1208,10 +1209,30 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
         rv[t] = res ? *reinterpret_cast<const float4*>(res + (size_t)row * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __builtin_amdgcn_sched_barrier(0);  // (keeps every load above ahead of the first use)
+    if (LN) {  // LayerNorm over the K channels of a row (its four kg lanes); the affine part is folded into W and bias
+        float sm = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 8 * KS; ++k2) sm += xf[k2];
+        sm += __shfl_xor(sm, 16);
+        sm += __shfl_xor(sm, 32);
+        const float mean = sm / (float)K;
+        float q2 = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 8 * KS; ++k2) {
+            const float d = xf[k2] - mean;
+            q2 += d * d;
+        }
+        q2 += __shfl_xor(q2, 16);
+        q2 += __shfl_xor(q2, 32);
+        const float rstd = 1.0f / sqrtf(q2 / (float)K + 1e-5f);
+#pragma unroll
+        for (int k2 = 0; k2 < 8 * KS; ++k2) xf[k2] = (xf[k2] - mean) * rstd;
+    }
     float amax = 0.f;
 #pragma unroll
     for (int k = 0; k < 8 * KS; ++k) amax = fmaxf(amax, fabsf(xf[k]));
-    const bool bad = !(amax < 32768.f) || (amax > 0.f && amax < 0.00390625f);
+    // (normalised rows are O(1) by construction: inside the split's range, see k_attn_block_small)
+    const bool bad = !LN && (!(amax < 32768.f) || (amax > 0.f && amax < 0.00390625f));
     f32x4 acc[NCT];
 #pragma unroll
     for (int t = 0; t < NCT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1258,15 +1279,21 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
                                acc[t][3] * scale + bv[t].w);
         if (res) { v.x += rv[t].x; v.y += rv[t].y; v.z += rv[t].z; v.w += rv[t].w; }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(out + (size_t)row * N + n) = v;
+        size_t at = (size_t)row * N + n;
+        if (QKV) {  // columns [q | k | v] x heads x qkv_hd -> out[which][image * heads + head][token][qkv_hd]
+            const int C = N / 3, which = n / C, cc = n - which * C, head = cc / qkv_hd, d = cc - head * qkv_hd;
+            const int b = row / qkv_L, l = row - b * qkv_L;
+            at = (size_t)which * M * C + (size_t)b * qkv_L * C + (size_t)head * qkv_L * qkv_hd + (size_t)l * qkv_hd + d;
+        }
+        *reinterpret_cast<float4*>(out + at) = v;
     }
 }
 
-// K = 128 / 256 / 512, N a multiple of what a wave takes at that K, and at most 8192 rows (beyond that k_igemm's tiles
-// are the better shape).
+// K = 64 / 128 / 256 / 512 with N a multiple of what a wave takes at that K, and few enough rows that k_igemm's tiles are
+// not the better shape (8192; 16384 at K = 64, where k_igemm has a single chunk to work on).
 bool proj_small_supported(int M, int N, int K) {
-    const int per_wave = K == 128 ? 128 : K == 256 ? 64 : K == 512 ? 32 : 0;
-    return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= 8192 && (long)M * N < (1l << 30);
+    const int per_wave = K == 64 ? 64 : K == 128 ? 128 : K == 256 ? 64 : K == 512 ? 32 : 0;
+    return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= (K == 64 ? 16384 : 8192);
 }
 
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
@@ -1274,13 +1301,29 @@ hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w
     if (!proj_small_supported(M, N, K) || !w_frag || !w) return hipErrorInvalidValue;
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
-    // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512
-    if (K == 128)
-        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+    // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512 (64 at K = 64)
+    if (K == 64)
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+    else if (K == 128)
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
     else if (K == 256)
-        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
     else
-        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu);
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+    return hipGetLastError();
+}
+
+// The LayerNorm-fused QKV projection of a 64-channel block on few rows (<= 16384 tokens): one wave per 16 tokens forms
+// all 192 columns and stores them head-split, qkv[which][image * heads + head][token][head_dim].
+bool qkv_small_supported(int M, int C, int L, int hd) {
+    return C == 64 && M >= 1 && M <= 16384 && hd % 4 == 0 && C % hd == 0 && L >= 1 && M % L == 0;
+}
+hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
+                            int M, int C, int L, int hd, hipStream_t stream) {
+    if (!qkv_small_supported(M, C, L, hd) || !w_frag || !w) return hipErrorInvalidValue;
+    const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
+    DANRA_LAUNCH_KERNEL((k_proj_small<2, 12, true, true>), dim3((M + 15) / 16), dim3(64), 0, stream, x, wf, w, wscale, bias,
+                        (const float*)nullptr, qkv, M, 3 * C, 0, L, hd);
     return hipGetLastError();
 }
 

@@ -1293,6 +1293,31 @@ __global__ __launch_bounds__(256) void k_split_to_frag16(const _Float16* __restr
         *reinterpret_cast<uint4*>(dst + 512) = *reinterpret_cast<const uint4*>(src + 64);
     }
 }
+// The same fragment order straight from the fp32 matrix (for matrices whose split copy is in another layout):
+// hi = scale * w rounded towards zero to fp16, lo = the remainder, as k_split_weights forms them.
+__global__ __launch_bounds__(256) void k_frag16_from_f32(const float* __restrict__ w, _Float16* __restrict__ out, int rows,
+                                                         int K, float scale) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const int KS = K / 32;
+    const size_t total = (size_t)rows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+        const float v = w[i] * scale;  // exact: a power of two
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+        const int T = n >> 4, c = n & 15, s2 = k >> 5, kg = (k & 31) >> 3, e = k & 7;
+        _Float16* dst = out + ((size_t)T * KS + s2) * 1024 + (kg * 16 + c) * 8 + e;
+        dst[0] = (_Float16)h[0];
+        dst[512] = (_Float16)(v - (float)h[0]);
+    }
+}
+hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, float scale, hipStream_t stream) {
+    if (rows % 16 || K % 32) return hipErrorInvalidValue;
+    int blocks = (int)(((size_t)rows * K + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_frag16_from_f32, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), rows, K, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_split_to_frag16(const float* split, float* out, int rows, int K, hipStream_t stream) {
     if (rows % 16 || K % 64) return hipErrorInvalidValue;
     int blocks = (int)(((size_t)rows * (K / 8) + 255) / 256);

@@ -28,9 +28,9 @@ def main():
         tot += d
         name = r["Kernel_Name"].split("(")[0].replace("danra::", "").replace("void ", "")
         if name.startswith("_ZN5danra"):  # a name the profiler's demangler gave up on (an _Float16 parameter)
-            m = re.match(r"_ZN5danra\d+([a-z_0-9]+?)I((?:Li\d+E)*)E", name)
+            m = re.match(r"_ZN5danra\d+([a-z_0-9]+?)I((?:L[ib]\d+E)*)E", name)
             if m:
-                name = m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
+                name = m.group(1) + "<" + ", ".join(re.findall(r"L[ib](\d+)E", m.group(2))) + ">"
         per[name][0] += 1
         per[name][1] += d
         if not brief:
