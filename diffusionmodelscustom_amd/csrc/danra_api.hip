@@ -86,6 +86,7 @@ struct DecP {
     float* wt = nullptr;  // [4*Cin][Cin]
     float* bt = nullptr;  // [4*Cin]
     SplitW s_wt;
+    float* wt_frag = nullptr;  // the transposed convolution's matrix in fragment order for k_proj_small (Cin = 64), or null
     ConvP conv;
     AttnP attn;
     int Cin = 0, Cout = 0;
@@ -425,6 +426,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         d.conv.w = bp.take((size_t)d.Cout * d.Cin * 9);
         d.conv.bias = bp.take(d.Cout);
         want_split(d.s_wt, d.wt, (size_t)4 * d.Cin, d.Cin, true);
+        d.wt_frag = d.Cin == 64 ? bh.take((size_t)4 * d.Cin * d.Cin) : nullptr;
         want_split(d.conv.split, d.conv.w, d.Cout, (size_t)9 * d.Cin);
         if (fill) {
             HIP_TRY(launch_pack_convT(src_of(h, p + ".transpose.weight"), src_of(h, p + ".transpose.bias"), d.wt, d.bt,
@@ -910,7 +912,12 @@ int run_decoder_block(danra_handle_s* h, int k, const float* in, const float* sk
         // the convolution gains, 2 us each, and at 32x32 more: +6 against -3.4 us)
         normalised = H2 * W2 <= 64;
         // (... and when the transposed convolution is split over K, that block sums its slabs as well)
-        RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt, normalised ? &up_slabs : nullptr));
+        if (d.wt_frag && h->fused_small_attention && !igemm_fp32_products_forced() &&
+            proj_small_supported(B * Hh * Ww, 4 * d.Cin, d.Cin))  // 64 channels: bound by its store, one trip to memory per wave
+            HIP_TRY(launch_proj_small(in, d.wt_frag, d.wt, d.s_wt.inv_scale, d.bt, nullptr, ws.up, B * Hh * Ww, 4 * d.Cin, d.Cin,
+                                      0, st, Hh, Ww));
+        else
+            RC_TRY(run_convT(h, d.wt, d.bt, d.Cin, in, ws.up, B, Hh, Ww, st, &d.s_wt, normalised ? &up_slabs : nullptr));
         HIP_TRY(launch_in_stats(up_slabs.count ? ws.partial : ws.up, ws.mean1, ws.rstd1, ws.stats_part, ws.stats_part_floats,
                                 B, H2 * W2, d.Cin, st, normalised ? ws.up : nullptr, nullptr, nullptr, 0,
                                 up_slabs.count ? &up_slabs : nullptr));
@@ -1134,6 +1141,10 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
     RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
     for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
+    for (DecP& d : h->dec) {
+        if (d.wt_frag && !d.s_wt.wh) d.wt_frag = nullptr;
+        if (d.wt_frag) HIP_TRY(launch_frag16_from_f32(d.wt, d.wt_frag, 4 * d.Cin, d.Cin, 1.0f / d.s_wt.inv_scale, st));
+    }
     for (AttnP& at : h->attn) {  // (an all-zero or non-finite matrix has no split copy and keeps the fp32 form)
         if (at.w_in_frag && !at.s_in.wh) at.w_in_frag = nullptr;
         if (at.w_out_frag && !at.s_out.wh) at.w_out_frag = nullptr;

@@ -128,7 +128,7 @@ bool igemm_fp32_products_forced();
 // out = act(A W^T + bias + res) for products with few rows (K = 128 / 256 / 512, M <= 8192; see proj_small_supported):
 // the output projections of the short-sequence attention blocks.  w_frag = W split in fp16 halves in fragment order
 // (scale 1 / wscale), w = the fp32 matrix (for rows outside the split's range).
-// (K = 64 as well, up to 16384 rows: the 64-channel blocks of the 16x16 maps)
+// (K = 64 as well, up to 65536 rows: the output projections of the 64-channel blocks)
 bool proj_small_supported(int M, int N, int K);
 // The LayerNorm-fused QKV projection of a 64-channel block on <= 16384 tokens through the same kernel: x [M][64], w_frag /
 // w / bias = in_proj [192][64] with the LayerNorm affine folded in, qkv [3][M / L * heads][L][hd].
@@ -137,8 +137,11 @@ hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w,
                             int M, int C, int L, int hd, hipStream_t stream);
 // w [rows][K] fp32 -> scale * w split in fp16 halves in the fragment order of launch_split_to_frag16 (rows % 16 == 0, K % 32 == 0)
 hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, float scale, hipStream_t stream);
+// With ct_W != 0: a kernel-2 stride-2 transposed convolution on a ct_H x ct_W map (N = 4 x channels), rows stored
+// pixel-shuffled (see k_proj_small).
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
-                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream);
+                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream, int ct_H = 0,
+                             int ct_W = 0);
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,

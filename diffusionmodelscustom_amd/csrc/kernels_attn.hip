@@ -1163,14 +1163,16 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
 // with its split-K reduction at 256 rows, 11.7; four waves per workgroup on a quarter of the CUs took 9.2).  A wave whose rows leave the range of the split (a value >= 2^15 or non-finite, or nothing but values below
 // 2^-8 that are not all zero) multiplies with fp32 instructions from the fp32 matrix instead.
 //   A [M][K], Wf = W [N][K] split and in fragment order (scale 1 / wscale), W the fp32 matrix, res [M][N] or null
-// (The transposed convolutions of the small decoder maps, 1024 such waves each, are not faster this way than through
-// k_igemm - 9.2-11.0 against 8.2-10.5 us: every wave fetches its weights again.)
+// With ct_W != 0 the product is a kernel-2 stride-2 transposed convolution on a ct_H x ct_W map (N = 4 x channels,
+// column = (dy, dx, channel)) and the rows are stored pixel-shuffled: out [B][2 ct_H][2 ct_W][N / 4].  That pays at
+// K = 64 only (bound by its 16 MB store); with K >= 128 the 1024 waves of such a product each fetch 32-64 KB of weights
+// again and k_igemm is as fast or faster (9.2-11.0 against 8.2-10.5 us).
 template <int KS, int NCT, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, const _Float16* __restrict__ Wf,
                                                     const float* __restrict__ W, float wscale,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                     float* __restrict__ out, int M, int N, int relu, int qkv_L,
-                                                    int qkv_hd) {
+                                                    int qkv_hd, int ct_H, int ct_W) {
     constexpr int K = 32 * KS;
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
     const int task = blockIdx.x;  // one wave per workgroup: a few hundred tasks spread over all CUs
@@ -1285,37 +1287,48 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
             const int b = row / qkv_L, l = row - b * qkv_L;
             at = (size_t)which * M * C + (size_t)b * qkv_L * C + (size_t)head * qkv_L * qkv_hd + (size_t)l * qkv_hd + d;
         }
+        if (!QKV && ct_W) {  // kernel-2 stride-2 transposed convolution: column (dy, dx, co) of coarse pixel (b, y, x)
+            const int Cc = N >> 2, hw = ct_H * ct_W;
+            const int q = n / Cc, co = n - q * Cc;
+            const int b = row / hw, r = row - b * hw, y = r / ct_W, x = r - y * ct_W;
+            at = (((size_t)b * 2 * ct_H + 2 * y + (q >> 1)) * 2 * ct_W + 2 * x + (q & 1)) * Cc + co;
+        }
         *reinterpret_cast<float4*>(out + at) = v;
     }
 }
 
 // K = 64 / 128 / 256 / 512 with N a multiple of what a wave takes at that K, and few enough rows that k_igemm's tiles are
-// not the better shape (8192; 16384 at K = 64, where k_igemm has a single chunk to work on).
+// not the better shape (8192; 65536 at K = 64, where k_igemm has a single chunk to work on and the product is bound by
+// memory: 11.1 against 14.3 us for 65536 rows with a residual, 48 MB).
 bool proj_small_supported(int M, int N, int K) {
     const int per_wave = K == 64 ? 64 : K == 128 ? 128 : K == 256 ? 64 : K == 512 ? 32 : 0;
-    return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= (K == 64 ? 16384 : 8192);
+    return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= (K == 64 ? 65536 : 8192);
 }
 
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
-                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream) {
+                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream, int ct_H,
+                             int ct_W) {
     if (!proj_small_supported(M, N, K) || !w_frag || !w) return hipErrorInvalidValue;
+    if (ct_W && (res || N % 16 || ct_H <= 0 || M % (ct_H * ct_W))) return hipErrorInvalidValue;
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
     // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512 (64 at K = 64)
     if (K == 64)
-        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
     else if (K == 128)
-        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
     else if (K == 256)
-        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
     else
-        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
     return hipGetLastError();
 }
 
 // The LayerNorm-fused QKV projection of a 64-channel block on few rows (<= 16384 tokens): one wave per 16 tokens forms
 // all 192 columns and stores them head-split, qkv[which][image * heads + head][token][head_dim].
 bool qkv_small_supported(int M, int C, int L, int hd) {
+    // (at 65536 tokens the row-stationary k_gemm_k64, which stages the weights once per workgroup, is the faster one:
+    // 18-20 against 25.5 us)
     return C == 64 && M >= 1 && M <= 16384 && hd % 4 == 0 && C % hd == 0 && L >= 1 && M % L == 0;
 }
 hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
@@ -1323,7 +1336,7 @@ hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w,
     if (!qkv_small_supported(M, C, L, hd) || !w_frag || !w) return hipErrorInvalidValue;
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     DANRA_LAUNCH_KERNEL((k_proj_small<2, 12, true, true>), dim3((M + 15) / 16), dim3(64), 0, stream, x, wf, w, wscale, bias,
-                        (const float*)nullptr, qkv, M, 3 * C, 0, L, hd);
+                        (const float*)nullptr, qkv, M, 3 * C, 0, L, hd, 0, 0);
     return hipGetLastError();
 }
 
