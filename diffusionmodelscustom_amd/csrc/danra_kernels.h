@@ -130,8 +130,9 @@ bool igemm_fp32_products_forced();
 // (scale 1 / wscale), w = the fp32 matrix (for rows outside the split's range).
 // (K = 64 as well, up to 65536 rows: the output projections of the 64-channel blocks)
 bool proj_small_supported(int M, int N, int K);
-// The LayerNorm-fused QKV projection of a 64-channel block on <= 16384 tokens through the same kernel: x [M][64], w_frag /
-// w / bias = in_proj [192][64] with the LayerNorm affine folded in, qkv [3][M / L * heads][L][hd].
+// The LayerNorm-fused QKV projection of an attention block on few tokens (C = 64: <= 16384, C = 128 / 256 / 512: <= 8192)
+// through the same kernel: x [M][C], w_frag / w / bias = in_proj [3C][C] with the LayerNorm affine folded in,
+// qkv [3][M / L * heads][L][hd].
 bool qkv_small_supported(int M, int C, int L, int hd);
 hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
                             int M, int C, int L, int hd, hipStream_t stream);

@@ -1324,19 +1324,30 @@ hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w
     return hipGetLastError();
 }
 
-// The LayerNorm-fused QKV projection of a 64-channel block on few rows (<= 16384 tokens): one wave per 16 tokens forms
-// all 192 columns and stores them head-split, qkv[which][image * heads + head][token][head_dim].
+// The LayerNorm-fused QKV projection of an attention block on few rows through the same kernel: a wave normalises its 16
+// tokens in registers, forms 192 / 128 / 64 / 32 of the 3 C columns (C = 64 / 128 / 256 / 512) and stores them head-split,
+// qkv[which][image * heads + head][token][head_dim].
 bool qkv_small_supported(int M, int C, int L, int hd) {
-    // (at 65536 tokens the row-stationary k_gemm_k64, which stages the weights once per workgroup, is the faster one:
-    // 18-20 against 25.5 us)
-    return C == 64 && M >= 1 && M <= 16384 && hd % 4 == 0 && C % hd == 0 && L >= 1 && M % L == 0;
+    // (at 65536 tokens of 64 channels the row-stationary k_gemm_k64, which stages the weights once per workgroup, is the
+    // faster one: 18-20 against 25.5 us)
+    const int max_rows = C == 64 ? 16384 : 8192;
+    return (C == 64 || C == 128 || C == 256 || C == 512) && M >= 1 && M <= max_rows && hd % 4 == 0 && C % hd == 0 && L >= 1 &&
+           M % L == 0;
 }
 hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
                             int M, int C, int L, int hd, hipStream_t stream) {
     if (!qkv_small_supported(M, C, L, hd) || !w_frag || !w) return hipErrorInvalidValue;
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
-    DANRA_LAUNCH_KERNEL((k_proj_small<2, 12, true, true>), dim3((M + 15) / 16), dim3(64), 0, stream, x, wf, w, wscale, bias,
-                        (const float*)nullptr, qkv, M, 3 * C, 0, L, hd, 0, 0);
+    const int rts = (M + 15) / 16;
+    const float* none = nullptr;
+    if (C == 64)
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 12, true, true>), dim3(rts), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+    else if (C == 128)
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+    else if (C == 256)
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true, true>), dim3(rts * 12), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+    else
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true, true>), dim3(rts * 48), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
     return hipGetLastError();
 }
 
