@@ -311,7 +311,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         want_split(a.s_in, a.w_in, (size_t)3 * C, C, true);
         want_split(a.s_out, a.w_out, C, C, true);
         // (filled behind split_registered; the shapes attn_block_small_supported knows)
-        a.w_in_frag = (h->cfg.n_heads == 4 && (C == 128 || C == 256 || C == 512)) ? bh.take((size_t)3 * C * C) : nullptr;
+        a.w_in_frag = (C == 128 || C == 256 || C == 512) ? bh.take((size_t)3 * C * C) : nullptr;
         a.w_out_frag = (C == 128 || C == 256 || C == 512) ? bh.take((size_t)C * C) : nullptr;
         if (C == 64) {  // (the K = 64 split copies are in k_gemm_k64's own order: these come from the fp32 matrices)
             a.w_in_frag = bh.take((size_t)3 * C * C);

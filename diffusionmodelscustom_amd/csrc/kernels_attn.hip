@@ -923,7 +923,7 @@ static hipError_t launch_attn_small(const float* q, const float* k, const float*
 // row whose variance is far below the LayerNorm's epsilon is kept to an absolute 2^-25, which is what fp32 keeps of
 // it next to the bias.  The attention part is k_attn_reg reading LDS: one wave per 16-query tile, scores in
 // registers, exact two-pass softmax, fp32 matrix instructions.
-template <int NT, int C, int HD, int NW, int LIMG = 16 * NT>
+template <int NT, int C, int HD, int NW>
 __global__ __launch_bounds__(64 * NW) void k_attn_block_small(const float* __restrict__ X, const _Float16* __restrict__ Wf,
                                                           float wscale, const float* __restrict__ bin,
                                                           float* __restrict__ O, int heads, float scale_log2e) {
@@ -938,7 +938,6 @@ __global__ __launch_bounds__(64 * NW) void k_attn_block_small(const float* __res
     constexpr int NIT = (NTILES + NW - 1) / NW;  // column tiles per wave
     constexpr int RING = NIT < (16 / KS > 1 ? 16 / KS : 1) ? NIT : (16 / KS > 1 ? 16 / KS : 1);  // weight tiles in flight per wave (8 * KS registers each)
     static_assert(NT <= NW && (NW == 4 || NW == 8), "one wave per token tile");
-    static_assert(LIMG == L || (NT == 1 && LIMG == 4), "a workgroup holds one image, or four images of four tokens");
     static_assert(HD % 16 == 0 && C % 64 == 0, "tile sizes");
     __shared__ __attribute__((aligned(16))) float qkv[L * LDQ];
     __shared__ __attribute__((aligned(16))) _Float16 xs[L * XP];
@@ -1094,7 +1093,6 @@ __global__ __launch_bounds__(64 * NW) void k_attn_block_small(const float* __res
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < HQ; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s2], q[s2], acc, 0, 0, 0);
-        if (LIMG == 4 && kg != (c >> 2)) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // keys 4 kg .. of another image
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
         st[kt] = acc;
@@ -1131,11 +1129,14 @@ __global__ __launch_bounds__(64 * NW) void k_attn_block_small(const float* __res
         *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv);
 }
 
-// The shapes the fused block kernel is built for: 64 tokens x 128 channels, 16 tokens x 256 channels and 4 tokens x 512
-// channels with four heads - the 8x8, 4x4 and 2x2 levels of a 64x64 input.  At 4 tokens a workgroup takes four images
-// (one 16-token tile; their rows are contiguous) and the scores between tokens of different images are masked out.
+// The shapes the fused block kernel is built for: 64 tokens x 128 channels and 16 tokens x 256 channels with four heads -
+// the 8x8 and 4x4 levels of a 64x64 input.  (A form for 4 tokens x 512 channels - four images per workgroup, the scores
+// between tokens of different images masked out - streamed 786 KB of weights through each of only B/4 x heads
+// workgroups: 20.4 us at 64 images, against 10.0 + 4.8 us for k_proj_small's QKV projection, which spreads the same
+// weights over 768 waves, and k_attn_reg.)
 bool attn_block_small_supported(int B, int L, int C, int heads) {
-    return heads == 4 && ((L == 64 && C == 128) || (L == 16 && C == 256) || (L == 4 && C == 512 && B % 4 == 0));
+    (void)B;
+    return heads == 4 && ((L == 64 && C == 128) || (L == 16 && C == 256));
 }
 
 hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float wscale, const float* b_in, float* o,
@@ -1145,10 +1146,8 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
     const _Float16* wh = reinterpret_cast<const _Float16*>(w_in_frag);
     if (L == 64)
         DANRA_LAUNCH_KERNEL((k_attn_block_small<4, 128, 32, 4>), dim3(B * heads), dim3(256), 0, stream, x, wh, wscale, b_in, o, heads, scale_log2e);
-    else if (L == 16)
-        DANRA_LAUNCH_KERNEL((k_attn_block_small<1, 256, 64, 8>), dim3(B * heads), dim3(512), 0, stream, x, wh, wscale, b_in, o, heads, scale_log2e);
     else
-        DANRA_LAUNCH_KERNEL((k_attn_block_small<1, 512, 128, 8, 4>), dim3(B / 4 * heads), dim3(512), 0, stream, x, wh, wscale, b_in, o, heads, scale_log2e);
+        DANRA_LAUNCH_KERNEL((k_attn_block_small<1, 256, 64, 8>), dim3(B * heads), dim3(512), 0, stream, x, wh, wscale, b_in, o, heads, scale_log2e);
     return hipGetLastError();
 }
 

@@ -89,13 +89,14 @@ def test_attention_batch_and_relu(cond64, dev):
     (6, "decoder.residual_layers.1.attention", 128, 8, 3),
     (3, "encoder.attention_layers.3", 256, 4, 6),                 # 16 tokens
     (5, "decoder.residual_layers.0.attention", 256, 4, 2),
-    (4, "encoder.attention_layers.4", 512, 2, 8),                 # 4 tokens: four images per workgroup, masked scores
-    (4, "encoder.attention_layers.4", 512, 2, 4),
-    (4, "encoder.attention_layers.4", 512, 2, 6),                 # batch not a multiple of 4: the three-kernel form
+    (4, "encoder.attention_layers.4", 512, 2, 8),                 # 4 tokens: QKV projection with one wave per 16 tokens of
+    (4, "encoder.attention_layers.4", 512, 2, 4),                 # (four images), attention per image
+    (4, "encoder.attention_layers.4", 512, 2, 6),                 # ragged last row tile
 ])
 def test_short_sequence_attention_blocks(cond64, dev, index, prefix, C, side, batch):
-    """LayerNorm + QKV projection + attention of the deep levels as one kernel per (image, head) (k_attn_block_small),
-    at batches > 1, against the restatement; images must not see each other where a workgroup holds four of them."""
+    """The attention blocks of the deep levels at batches > 1 against the restatement: LayerNorm + QKV projection +
+    attention as one kernel per (image, head) at 64 and 16 tokens (k_attn_block_small), one wave per 16 tokens for the QKV
+    and output projections elsewhere (k_proj_small: at 4 tokens a wave's tile holds four images)."""
     _, sd, ops = cond64
     x = gs.randn(300 + index + batch, batch, C, side, side)
     x[0, :, 0, 0] = 0.25          # a token whose channels are all equal: LayerNorm maps it to zero
@@ -491,9 +492,9 @@ def test_split_operand_convolution_value_ranges(cond64, dev, case):
 
 
 def test_fused_attention_blocks_equal_the_separate_kernels(cond64, dev, monkeypatch):
-    """A whole forward at the benchmark's batch (64 images: every fused short-sequence attention kernel runs, the 2x2
-    level with four images per workgroup) against a second engine created with DANRA_FUSED_SMALL_ATTENTION=0, whose
-    blocks run the LayerNorm-fused QKV GEMM and the attention kernel separately."""
+    """A whole forward at the benchmark's batch (64 images: the fused short-sequence attention kernels and every
+    one-trip projection kernel run) against a second engine created with DANRA_FUSED_SMALL_ATTENTION=0, whose blocks
+    run their projections as tiled GEMMs and the attention kernel separately."""
     model, _, _ = cond64
     B = 64
     inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64).items()}
@@ -506,7 +507,7 @@ def test_fused_attention_blocks_equal_the_separate_kernels(cond64, dev, monkeypa
         separate = other(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
     assert rel_err(fused, separate) < 2e-5
     assert not torch.equal(fused, separate), "the switch changed nothing: one of the two forms did not run"
-    for b in range(B):  # no image may be off on its own (a workgroup of the 2x2 level holds four of them)
+    for b in range(B):  # no image may be off on its own (a row tile of the 2x2 level holds four of them)
         assert rel_err(fused[b], separate[b]) < 1e-4, f"image {b}"
 
 
