@@ -72,6 +72,7 @@ struct AttnP {
     SplitW s_in, s_out, s_ff1, s_ff2;
     float* w_in_frag = nullptr;  // s_in in fragment order for the fused short-sequence kernel (launch_split_to_frag16), or null
     float* w_out_frag = nullptr; // s_out in fragment order for k_proj_small, or null
+    float *w_ff1_frag = nullptr, *w_ff2_frag = nullptr;  // the same for the feed-forward matrices (C >= 128)
     int C = 0;
 };
 struct BlockP {
@@ -324,6 +325,10 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
             a.b_ff2 = bp.take(C);
             want_split(a.s_ff1, a.w_ff1, C, C, true);
             want_split(a.s_ff2, a.w_ff2, C, C, true);
+            if (C == 128 || C == 256 || C == 512) {
+                a.w_ff1_frag = bh.take((size_t)C * C);
+                a.w_ff2_frag = bh.take((size_t)C * C);
+            }
         }
         if (fill) {
             const std::string m = p + mha_name(h);
@@ -792,7 +797,7 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     if (at.w_out_frag && h->fused_small_attention && !igemm_fp32_products_forced() && proj_small_supported(B * L, C, C)) {
         // few rows: the whole product as one trip to memory per wave instead of a tiled GEMM (+ split-K reduction)
         HIP_TRY(launch_proj_small(ws.obuf, at.w_out_frag, at.w_out, at.s_out.inv_scale, at.b_out, x, attended, B * L, C, C,
-                                  (relu && !ff) ? 1 : 0, st));
+                                  (relu && !ff) ? ACT_RELU : ACT_NONE, st));
         if (!ff) return DANRA_OK;
     } else {
     IGemmArgs o = blank_args();
@@ -803,6 +808,14 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
     choose_split(o, ws);
     RC_TRY(igemm(h, o, st));
     if (!ff) return DANRA_OK;
+    }
+    if (at.w_ff1_frag && at.w_ff2_frag && h->fused_small_attention && !igemm_fp32_products_forced() &&
+        proj_small_supported(B * L, C, C)) {  // few rows: both linears of the feed-forward part as one-trip kernels
+        HIP_TRY(launch_proj_small(attended, at.w_ff1_frag, at.w_ff1, at.s_ff1.inv_scale, at.b_ff1, nullptr, ws.obuf, B * L, C, C,
+                                  ACT_GELU, st, 0, 0, true));
+        HIP_TRY(launch_proj_small(ws.obuf, at.w_ff2_frag, at.w_ff2, at.s_ff2.inv_scale, at.b_ff2, attended, out, B * L, C, C,
+                                  relu ? ACT_RELU : ACT_NONE, st));
+        return DANRA_OK;
     }
     IGemmArgs f1 = blank_args();
     f1.A = attended; f1.lda = C; f1.ln = 1; f1.a_mode = A_GEMM;
@@ -1155,6 +1168,10 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
         }
         if (at.w_in_frag) HIP_TRY(launch_split_to_frag16(at.s_in.wh, at.w_in_frag, 3 * at.C, at.C, st));
         if (at.w_out_frag) HIP_TRY(launch_split_to_frag16(at.s_out.wh, at.w_out_frag, at.C, at.C, st));
+        if (at.w_ff1_frag && !at.s_ff1.wh) at.w_ff1_frag = nullptr;
+        if (at.w_ff2_frag && !at.s_ff2.wh) at.w_ff2_frag = nullptr;
+        if (at.w_ff1_frag) HIP_TRY(launch_split_to_frag16(at.s_ff1.wh, at.w_ff1_frag, at.C, at.C, st));
+        if (at.w_ff2_frag) HIP_TRY(launch_split_to_frag16(at.s_ff2.wh, at.w_ff2_frag, at.C, at.C, st));
     }
     h->freq_dirty = true;
     RC_TRY(upload_freq(h, st));

@@ -140,9 +140,11 @@ hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w,
 hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, float scale, hipStream_t stream);
 // With ct_W != 0: a kernel-2 stride-2 transposed convolution on a ct_H x ct_W map (N = 4 x channels), rows stored
 // pixel-shuffled (see k_proj_small).
+// act: an Activation; layernorm: the rows are normalised over their K channels first (K >= 128; the affine part is
+// folded into w and bias), as the feed-forward part of an attention block needs it.
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
-                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream, int ct_H = 0,
-                             int ct_W = 0);
+                             const float* res, float* out, int M, int N, int K, int act, hipStream_t stream, int ct_H = 0,
+                             int ct_W = 0, bool layernorm = false);
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,

@@ -1166,11 +1166,14 @@ hipError_t launch_attn_block_small(const float* x, const float* w_in_frag, float
 // column = (dy, dx, channel)) and the rows are stored pixel-shuffled: out [B][2 ct_H][2 ct_W][N / 4].  That pays at
 // K = 64 only (bound by its 16 MB store); with K >= 128 the 1024 waves of such a product each fetch 32-64 KB of weights
 // again and k_igemm is as fast or faster (9.2-11.0 against 8.2-10.5 us).
+// Exact (erf) GELU, as torch.nn.GELU() evaluates it.
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
 template <int KS, int NCT, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, const _Float16* __restrict__ Wf,
                                                     const float* __restrict__ W, float wscale,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                    float* __restrict__ out, int M, int N, int relu, int qkv_L,
+                                                    float* __restrict__ out, int M, int N, int act, int qkv_L,
                                                     int qkv_hd, int ct_H, int ct_W) {
     constexpr int K = 32 * KS;
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
@@ -1279,7 +1282,8 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
         float4 v = make_float4(acc[t][0] * scale + bv[t].x, acc[t][1] * scale + bv[t].y, acc[t][2] * scale + bv[t].z,
                                acc[t][3] * scale + bv[t].w);
         if (res) { v.x += rv[t].x; v.y += rv[t].y; v.z += rv[t].z; v.w += rv[t].w; }
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         size_t at = (size_t)row * N + n;
         if (QKV) {  // columns [q | k | v] x heads x qkv_hd -> out[which][image * heads + head][token][qkv_hd]
             const int C = N / 3, which = n / C, cc = n - which * C, head = cc / qkv_hd, d = cc - head * qkv_hd;
@@ -1305,21 +1309,33 @@ bool proj_small_supported(int M, int N, int K) {
 }
 
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
-                             const float* res, float* out, int M, int N, int K, int relu, hipStream_t stream, int ct_H,
-                             int ct_W) {
+                             const float* res, float* out, int M, int N, int K, int act, hipStream_t stream, int ct_H,
+                             int ct_W, bool layernorm) {
     if (!proj_small_supported(M, N, K) || !w_frag || !w) return hipErrorInvalidValue;
     if (ct_W && (res || N % 16 || ct_H <= 0 || M % (ct_H * ct_W))) return hipErrorInvalidValue;
+    if (layernorm) {  // rows normalised over their K channels first (the affine part folded into W and bias)
+        if (ct_W || K == 64) return hipErrorInvalidValue;
+        const _Float16* wfl = reinterpret_cast<const _Float16*>(w_frag);
+        const int rtl = (M + 15) / 16;
+        if (K == 128)
+            DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true>), dim3(rtl * (N / 128)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+        else if (K == 256)
+            DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true>), dim3(rtl * (N / 64)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+        else
+            DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true>), dim3(rtl * (N / 32)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+        return hipGetLastError();
+    }
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
     // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512 (64 at K = 64)
     if (K == 64)
-        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
     else if (K == 128)
-        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
     else if (K == 256)
-        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
     else
-        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, relu, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
     return hipGetLastError();
 }
 
