@@ -1340,7 +1340,7 @@ hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w
 }
 
 // The LayerNorm-fused QKV projection of an attention block on few rows through the same kernel: a wave normalises its 16
-// tokens in registers, forms 192 / 128 / 64 / 32 of the 3 C columns (C = 64 / 128 / 256 / 512) and stores them head-split,
+// tokens in registers, forms 64 / 128 / 64 / 32 of the 3 C columns (C = 64 / 128 / 256 / 512) and stores them head-split,
 // qkv[which][image * heads + head][token][head_dim].
 bool qkv_small_supported(int M, int C, int L, int hd) {
     // (at 65536 tokens of 64 channels the row-stationary k_gemm_k64, which stages the weights once per workgroup, is the
@@ -1355,8 +1355,8 @@ hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w,
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
     const float* none = nullptr;
-    if (C == 64)
-        DANRA_LAUNCH_KERNEL((k_proj_small<2, 12, true, true>), dim3(rts), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+    if (C == 64)  // three waves per 16 tokens (q, k, v; each normalises the rows again): 64 registers instead of 172, 9.2 against 9.6 us
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
     else if (C == 128)
         DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
     else if (C == 256)
