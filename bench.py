@@ -80,18 +80,37 @@ def unet_flops_per_image(size, in_ch, attn_ff=False):
     return fl
 
 
+def library_sha256():
+    """Hash of the library file this process runs (the one diffusionmodelscustom_amd.hip_engine loads)."""
+    import hashlib
+    from diffusionmodelscustom_amd import hip_engine
+    with open(hip_engine.library_path(), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def family_traffic_per_launch(workload, batch, family):
-    """HBM bytes per launch of the timed kernel family from the committed PMC measurement (rocprofv3 --pmc FETCH_SIZE
-    with the gfx950 x2 correction, and WRITE_SIZE, in separate passes: tools/pmc_traffic.sh), averaged over the launches
-    of a UNet evaluation like `achieved`.  Only measured for the conditional 64x64 workload (c3) at batch 64."""
-    path = os.path.join(ROOT, "profiles", "r02_family_traffic.json")
-    if workload != "c3" or batch != 64 or not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        t = json.load(fh).get(family)
+    """HBM bytes per launch of the timed kernel family from the newest committed PMC measurement (rocprofv3 --pmc
+    FETCH_SIZE with the gfx950 x2 correction, and WRITE_SIZE, in separate passes: tools/pmc_traffic.sh), averaged over
+    the launches of a UNet evaluation like `achieved`.  It is a STATIC figure, measured once for the conditional 64x64
+    workload (c3) at batch 64, so it is quoted only when the file names the library that is running now (sha256 of
+    the .so written by tools/pmc_summary.py); otherwise `traffic` is null and `traffic_note` says why."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_family_traffic.json")))
+    if workload != "c3" or batch != 64:
+        return {"traffic": None, "traffic_note": "PMC traffic is only measured for workload c3 at batch 64"}
+    if not files:
+        return {"traffic": None, "traffic_note": "no committed PMC measurement"}
+    with open(files[-1]) as fh:
+        doc = json.load(fh)
+    t = doc.get(family)
+    name = os.path.relpath(files[-1], ROOT)
     if not t:
-        return None
-    return {"traffic": t["bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC, " + t["source"] + ")"}
+        return {"traffic": None, "traffic_note": f"{name} holds no entry for this kernel family"}
+    if doc.get("library_sha256") != library_sha256():
+        return {"traffic": None, "traffic_note": f"{name} was measured on another build of the library (sha256 "
+                f"{str(doc.get('library_sha256'))[:16]}, running {library_sha256()[:16]}): regenerate it with tools/pmc_traffic.sh"}
+    return {"traffic": t["bytes_per_launch"], "traffic_static": True,
+            "traffic_unit": f"HBM bytes per launch: static PMC measurement of this library build ({name}; " + t["source"] + ")"}
 
 
 def build_model(w, seed):
@@ -181,6 +200,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-strict-fp32", action="store_true", help="skip the fp32-instructions-only twin measurement")
+    ap.add_argument("--strict-calls", type=int, default=3)
     ap.add_argument("--roofline-kernel", default="igemm", choices=["igemm", "flash"],
                     help="the kernel family timed for `roofline`: the implicit GEMMs (largest share of GPU time) or the "
                          "flash attention kernels")
@@ -251,6 +272,27 @@ def main():
     kern_bytes = 0.0 if args.no_kernel_timing else engine.profile_bytes()
     assert torch.isfinite(out).all()
 
+    # The same workload with every product on fp32 matrix instructions (danra_set_fp32_products(1): no fp16 split
+    # anywhere), timed in the same process: one warm-up call (its graph is captured anew), then `strict_calls` calls.
+    strict = None
+    if world == 1 and not args.no_strict_fp32:
+        engine.lib.danra_set_fp32_products(1)
+        try:
+            one_step()
+            fence()
+            ts = time.perf_counter()
+            for _ in range(args.strict_calls):
+                out32 = one_step()
+            fence()
+            strict_elapsed = time.perf_counter() - ts
+            assert torch.isfinite(out32).all()
+        finally:
+            engine.lib.danra_set_fp32_products(0)
+        strict = {"value": B * args.strict_calls / strict_elapsed, "unit": "images/sec",
+                  "ms_per_step": 1e3 * strict_elapsed / args.strict_calls,
+                  "unet_ms": 1e3 * strict_elapsed / args.strict_calls / (T - 1), "calls": args.strict_calls, "warmup": 1,
+                  "dtype": "f32 (fp32 matrix instructions only: danra_set_fp32_products(1))"}
+
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -272,7 +314,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (fp16 split-operand products: 22-bit operands, fp32 accumulate)",
             "data": "synthetic (seeded inputs, deterministic random-init weights, in-kernel Philox noise)" +
                     (" REHEARSAL: ranks share GPUs, gloo backend, not a measurement" if rehearsal else ""),
             "config": {"workload": w["name"], "timesteps": T, "batch_per_gpu": B, "global_batch": world * B,
@@ -322,9 +364,9 @@ def main():
                 "algorithmic_frac_of_fp32_peak": kern_flops / seconds / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
             }
             line["roofline"]["algorithmic_bytes_per_launch"] = kern_bytes / kern_launches
-            traffic = family_traffic_per_launch(args.workload, B, args.roofline_kernel)
-            if traffic:
-                line["roofline"].update(traffic)
+            line["roofline"].update(family_traffic_per_launch(args.workload, B, args.roofline_kernel))
+        if strict:
+            line["strict_fp32"] = strict
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

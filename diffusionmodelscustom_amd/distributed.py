@@ -58,27 +58,40 @@ def shard_batch(rank: int, world: int, *tensors):
 
 
 class _slice_of_global_batch:
-    """While this rank samples images [lo, hi) of a global batch: the in-kernel (Philox) draws are those of the global
-    elements (``diffusion.first_image``), and torch's generators - which the generic step loop draws its per-step noise
-    from - are forked and reseeded from (a number every identically seeded rank draws alike) + lo.  Without this, ranks
-    started with one ``torch.manual_seed`` would all add the same noise to their slices."""
+    """While this rank samples images [lo, hi) of a global batch.  Every identically seeded rank first draws ONE number
+    from torch's default generator, the number an unsharded ``sample()`` would draw as its Philox seed at this point.
+    The in-kernel (Philox) draws of the slice are then those of the global elements: that seed (unless the caller set
+    ``noise_seed``) with ``diffusion.first_image = lo``, so the slices get exactly the noise the unsliced batch would
+    get on one device.  torch's generators - which the generic step loop draws its per-step noise from - are forked
+    and reseeded from that number + lo; without this, ranks started with one ``torch.manual_seed`` would all add the
+    same noise to their slices."""
 
     def __init__(self, diffusion, lo):
         self.diffusion, self.lo = diffusion, lo
+        self.fork = None
 
     def __enter__(self):
         base = int(torch.randint(0, 2 ** 62, (1,)).item())  # advances every rank's generator by the same amount
-        self.saved_first = getattr(self.diffusion, "first_image", 0)
-        self.diffusion.first_image = self.lo
-        # only this process's device: forking every visible device would create a context on each of them
-        self.fork = torch.random.fork_rng(devices=[torch.cuda.current_device()] if torch.cuda.is_available() else [])
+        # fork only the generator of the device this sampler works on (none for a CPU run: asking for the current
+        # CUDA device would create a GPU context in a gloo-only process)
+        dev = torch.device(self.diffusion.device)
+        devices = [dev.index if dev.index is not None else torch.cuda.current_device()] if dev.type == "cuda" else []
+        self.fork = torch.random.fork_rng(devices=devices)
         self.fork.__enter__()
-        torch.manual_seed((base + 0x9E3779B97F4A7C15 * (self.lo + 1)) % (2 ** 63))
+        self.saved = (getattr(self.diffusion, "first_image", 0), getattr(self.diffusion, "noise_seed", None))
+        try:
+            torch.manual_seed((base + 0x9E3779B97F4A7C15 * (self.lo + 1)) % (2 ** 63))
+            self.diffusion.first_image = self.lo
+            if self.saved[1] is None:
+                self.diffusion.noise_seed = base
+        except BaseException:
+            self.__exit__(None, None, None)
+            raise
         return self
 
     def __exit__(self, *exc):
+        self.diffusion.first_image, self.diffusion.noise_seed = self.saved
         self.fork.__exit__(*exc)
-        self.diffusion.first_image = self.saved_first
         return False
 
 

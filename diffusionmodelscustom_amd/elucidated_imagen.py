@@ -9,10 +9,10 @@ lowres_cond_img, lowres_noise_times)`` and its ``lowres_cond`` / ``self_cond`` a
 runs in ``libdanra_hip.so`` is every statement of the sampling step around them.  Text conditioning enters as
 precomputed ``text_embeds`` (the T5 encoder is not part of this package), video and training are not covered.
 
-On CUDA float32 tensors ``one_unet_sample`` drives the HIP kernels (and raises if the library is missing: there is no
-software fallback on a GPU); on CPU tensors it evaluates the reference's torch statements.  All scalars of a step are
-formed on the host with the reference's own expressions on CPU tensors / Python floats, so that they round as in the
-reference's CPU run.
+``one_unet_sample`` drives the HIP kernels on CUDA float32 tensors and nothing else: it raises if the library is
+missing and it raises on a CPU device (there is no software sampler in this package; the CPU statement of the loop
+lives with the tests, as their checker).  All scalars of a step are formed on the host on one-element CPU tensors /
+Python floats, so that they round as in the reference's CPU run.
 """
 from collections import namedtuple
 from math import sqrt
@@ -140,13 +140,8 @@ class ElucidatedImagen(nn.Module):
     def threshold_x_start(self, x_start, dynamic_threshold=True):
         if not dynamic_threshold:
             return x_start.clamp(-1., 1.)
-        if _native(x_start):
-            x = x_start.contiguous()
-            s = hip_engine.edm_dynamic_threshold(x, self.dynamic_thresholding_percentile)
-        else:
-            s = torch.quantile(x_start.flatten(1).abs(), self.dynamic_thresholding_percentile, dim=-1)
-            s.clamp_(min=1.)
-        s = _pad_right(x_start, s)
+        _require_native(x_start, 'threshold_x_start')
+        s = _pad_right(x_start, hip_engine.edm_dynamic_threshold(x_start.contiguous(), self.dynamic_thresholding_percentile))
         return x_start.clamp(-s, s) / s
 
     def c_skip(self, sigma_data, sigma):
@@ -163,13 +158,19 @@ class ElucidatedImagen(nn.Module):
 
     def preconditioned_network_forward(self, unet_forward, noised_images, sigma, *, sigma_data, clamp=False,
                                        dynamic_threshold=True, **kwargs):
-        batch, device = noised_images.shape[0], noised_images.device
-        if isinstance(sigma, float):
-            sigma = torch.full((batch,), sigma, device=device)
-        padded_sigma = self.right_pad_dims_to_datatype(sigma)
-        net_out = unet_forward(self.c_in(sigma_data, padded_sigma) * noised_images, self.c_noise(sigma), **kwargs)
-        out = self.c_skip(sigma_data, padded_sigma) * noised_images + self.c_out(sigma_data, padded_sigma) * net_out
-        return self.threshold_x_start(out, dynamic_threshold) if clamp else out
+        """One denoiser evaluation at ONE noise level for the whole batch (a float, or a tensor whose entries are
+        equal): input scaling, network, output combination in the library's kernel, threshold."""
+        _require_native(noised_images, 'preconditioned_network_forward')
+        level = float(sigma if isinstance(sigma, float) else sigma.flatten()[0])
+        if torch.is_tensor(sigma) and not bool((sigma == sigma.flatten()[0]).all()):
+            raise NotImplementedError('one noise level per call: every image of a sampling batch is at the same level')
+        c_in, c_skip, c_out, c_noise = self._scalars(sigma_data, level)
+        x = noised_images.contiguous()
+        noise_cond = torch.full((x.shape[0],), c_noise, device=x.device, dtype=torch.float32)
+        net_out = unet_forward(x * c_in, noise_cond, **kwargs).contiguous()
+        out = torch.empty_like(x)
+        hip_engine.edm_precondition(x, net_out, out, c_skip, c_out, bool(clamp and not dynamic_threshold))
+        return self.threshold_x_start(out, True) if (clamp and dynamic_threshold) else out
 
     # ---- schedule (elucidated_imagen.py:376-390, :430-436)
     def sample_schedule(self, num_sample_steps, rho, sigma_min, sigma_max, device=None):
@@ -223,48 +224,10 @@ class ElucidatedImagen(nn.Module):
                      dynamic_threshold=dynamic_threshold, init_images=init_images, inpaint_images=inpaint_images,
                      inpaint_masks=inpaint_masks if has_inpainting else None, resample_times=resample_times,
                      net_kwargs=dict(cond_scale=cond_scale, **kwargs), draws=draws)
-        if device.type == 'cuda':
-            return self._one_unet_sample_hip(**state)
-        return self._one_unet_sample_torch(**state)
-
-    def _one_unet_sample_torch(self, *, unet, shape, hp, init_sigma, levels, clamp, dynamic_threshold, init_images,
-                               inpaint_images, inpaint_masks, resample_times, net_kwargs, draws):
-        """The reference's statements (CPU tensors, or comparisons)."""
-        images = init_sigma * draws.normal(shape)
-        if init_images is not None:
-            images += init_images
-        x_start = None
-        has_inpainting = inpaint_masks is not None
-        unet_kwargs = dict(sigma_data=hp.sigma_data, clamp=clamp, dynamic_threshold=dynamic_threshold, **net_kwargs)
-        for ind, (sigma, sigma_next, gamma) in enumerate(levels):
-            is_last_timestep = ind == len(levels) - 1
-            for r in reversed(range(resample_times)):
-                eps = hp.S_noise * draws.normal(shape)
-                sigma_hat = sigma + gamma * sigma
-                added_noise = sqrt(sigma_hat ** 2 - sigma ** 2) * eps
-                images_hat = images + added_noise
-                self_cond = x_start if getattr(unet, 'self_cond', False) else None
-                if has_inpainting:
-                    images_hat = images_hat * ~inpaint_masks + (inpaint_images + added_noise) * inpaint_masks
-                model_output = self.preconditioned_network_forward(unet.forward_with_cond_scale, images_hat, sigma_hat,
-                                                                   self_cond=self_cond, **unet_kwargs)
-                denoised_over_sigma = (images_hat - model_output) / sigma_hat
-                images_next = images_hat + (sigma_next - sigma_hat) * denoised_over_sigma
-                second_order = sigma_next != 0
-                if second_order:
-                    self_cond = model_output if getattr(unet, 'self_cond', False) else None
-                    model_output_next = self.preconditioned_network_forward(unet.forward_with_cond_scale, images_next,
-                                                                            sigma_next, self_cond=self_cond, **unet_kwargs)
-                    denoised_prime_over_sigma = (images_next - model_output_next) / sigma_next
-                    images_next = images_hat + 0.5 * (sigma_next - sigma_hat) * (denoised_over_sigma + denoised_prime_over_sigma)
-                images = images_next
-                if has_inpainting and not (r == 0 or is_last_timestep):
-                    images = images + (sigma - sigma_next) * draws.normal(shape)
-                x_start = model_output_next if second_order else model_output
-        images = images.clamp(-1., 1.)
-        if has_inpainting:
-            images = images * ~inpaint_masks + inpaint_images * inpaint_masks
-        return self.unnormalize_img(images)
+        if device.type != 'cuda':
+            raise NotImplementedError('the elucidated sampler of this package runs in libdanra_hip.so on a CUDA device; '
+                                      f'the model is on {device}')
+        return self._one_unet_sample_hip(**state)
 
     def _one_unet_sample_hip(self, *, unet, shape, hp, init_sigma, levels, clamp, dynamic_threshold, init_images,
                              inpaint_images, inpaint_masks, resample_times, net_kwargs, draws):
@@ -421,8 +384,10 @@ class ElucidatedImagen(nn.Module):
         return outputs if return_all_unet_outputs else outputs[-1]
 
 
-def _native(t):
-    return t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2
+def _require_native(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2):
+        raise NotImplementedError(f'{what} runs in libdanra_hip.so: it needs a CUDA float32 tensor, got '
+                                  f'{t.dtype} on {t.device}')
 
 
 class _Draws:
@@ -434,10 +399,16 @@ class _Draws:
         self.source = model.noise_source
         self.device = device
         self.count = 0
-        if model.noise_seed is not None:
-            self.seed = int(model.noise_seed)
-        else:
-            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._model_seed = model.noise_seed
+        self._seed = None
+
+    @property
+    def seed(self):
+        """The Philox seed of this call, drawn from torch's generator the first time a kernel asks for it (a call whose
+        draws come from `noise_source` or from torch.randn leaves the generator alone)."""
+        if self._seed is None:
+            self._seed = int(self._model_seed) if self._model_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        return self._seed
 
     def normal(self, shape):
         if self.source is not None:

@@ -326,7 +326,10 @@ class _TokenLinear(torch.autograd.Function):
                     _check(lib, lib.danra_linear(_ptr(dy2), _ptr(wt), None, _ptr(dx), M, K, N, _stream()), "danra_linear")
                 else:
                     dx = dy2.matmul(weight).view(ctx.x_shape)
-            if lib.danra_linear_wgrad_supported(M, N, K):
+            if not ctx.needs_input_grad[1]:
+                dw = None
+                db = dy2.sum(0) if ctx.needs_input_grad[2] else None
+            elif lib.danra_linear_wgrad_supported(M, N, K):
                 dw = torch.empty_like(weight)
                 db = torch.empty(N, device=x2.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
                 workspace = torch.empty(lib.danra_linear_wgrad_workspace(M, N, K) // 4, device=x2.device, dtype=torch.float32)

@@ -9,7 +9,8 @@ Two execution paths:
 * **HIP path** - ``DiffusionNet.forward`` on CUDA fp32 tensors in eval mode with gradients disabled
   (exactly the situation inside ``DiffusionUtils.sample``) runs entirely in ``libdanra_hip.so``
   (hand-written gfx950 kernels behind the C ABI of ``include/danra_hip.h``).  If the library is
-  missing this path raises; it never degrades to torch ops.
+  missing this path raises.  A network geometry the library does not take (``hip_supported``) or an input of another dtype or shape
+  is announced with a warning once and evaluated by the torch composition below.
 * **autograd path** - training mode, gradients enabled, or CPU tensors: a differentiable
   composition of torch ops with the reference's arithmetic, which is what the reference's training
   pipeline (training_DANRA_conditional.py:775-1016) needs for backward.

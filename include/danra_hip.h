@@ -6,9 +6,13 @@
  * entry point below names the reference Python interface it replaces (file:line relative to the
  * reference tree, DDPM_DANRA_conditional/).  All pointers named *_dev are device pointers owned
  * by the caller (PyTorch tensors in the shipped binding); the library borrows them for the call.
- * Everything is fp32 except the integer timestep / class tensors (int64, as torch.long).  (Storage and accumulation
- * are fp32 throughout; the two matrix products of the head_dim-16 attention core are evaluated as fp16 products of
- * operands split in two halves, 22 significant bits each, with an fp32 fallback when a value leaves the fp16 range.)
+ * Everything is fp32 except the integer timestep / class tensors (int64, as torch.long).  Storage and accumulation
+ * are fp32 throughout.  The large matrix products - every convolution but the stem, every projection and transposed
+ * convolution with 64 or more input channels, and both products of the head_dim-16 attention core - are by default
+ * evaluated on the fp16 matrix cores as three fp16 products of operands split in two fp16 halves (22 significant
+ * bits per operand, the low x low term dropped, fp32 accumulation), with a per-tile fallback to fp32 matrix
+ * instructions when a staged value leaves the range in which the split holds 22 bits (at or above 2^15, non-finite,
+ * or a tile that is uniformly tiny).  danra_set_fp32_products(1) makes every product an fp32 instruction.
  * Every function returns 0 on success or a negative DANRA_E* code and never throws;
  * danra_last_error() returns the message of the calling thread's last failure.
  * All kernels are enqueued on the hipStream_t passed as `stream` (void*, 0 = default stream);

@@ -162,3 +162,26 @@ def lowres_q_sample(x_start, t, noise):
     log_snr = beta_linear_log_snr(t).type(x_start.dtype).reshape(-1, 1, 1, 1)
     alpha, sigma = torch.sqrt(torch.sigmoid(log_snr)), torch.sqrt(torch.sigmoid(-log_snr))
     return alpha * x_start + sigma * noise
+
+
+def cascade_sample(nets, image_sizes, hparams, normal, *, batch_size, channels=3, lowres_sample_noise_level=0.2,
+                   self_cond=(), dynamic_thresholding=True, percentile=0.95, auto_normalize_img=True):
+    """elucidated_imagen.py:547-751 for unconditional images: stage k > 0 is given the previous stage's output, resized
+    (nearest) to its size, normalised and noised at `lowres_sample_noise_level` (one draw), then sampled with
+    one_unet_sample.  `nets[k](x, noise_cond, **kwargs)` stands for unet k's forward_with_cond_scale.  Returns every
+    stage's output."""
+    outputs, img = [], None
+    for k, (net, size, hp) in enumerate(zip(nets, image_sizes, hparams)):
+        kwargs = {}
+        if k > 0:
+            times = torch.full((batch_size,), lowres_sample_noise_level)
+            low = img if img.shape[-1] == size else F.interpolate(img, size, mode='nearest')
+            if auto_normalize_img:
+                low = low * 2. - 1.
+            kwargs = dict(lowres_cond_img=lowres_q_sample(low, times, normal(low.shape)), lowres_noise_times=times)
+        img, _ = one_unet_sample(net, (batch_size, channels, size, size), hp, normal,
+                                 self_cond_net=bool(self_cond[k]) if self_cond else False,
+                                 dynamic_threshold=dynamic_thresholding, percentile=percentile,
+                                 auto_normalize_img=auto_normalize_img, cond_scale=1., **kwargs)
+        outputs.append(img)
+    return outputs

@@ -1,7 +1,9 @@
-"""Host side of the elucidated (EDM) sampler without a GPU: the package's CPU path against the oracle's restatement of
-CascadedDDPM/elucidated_imagen.py (bit for bit: both evaluate torch CPU statements), the schedule's known end points,
-and the oracle's spelled-out quantile against torch.quantile.  Parity with the reference itself is unpinned for this
-path (see oracle/edm_ref.py)."""
+"""Host side of the elucidated (EDM) sampler without a GPU: the schedule's known end points against the oracle's
+restatement of CascadedDDPM/elucidated_imagen.py, the oracle's spelled-out quantile against torch.quantile, the
+low-resolution noising, and the refusal to sample on a CPU device (the sampler is a GPU path; its CPU statement is
+oracle/edm_ref.py, the checker of tests/test_gpu_edm.py).  Parity with the reference itself is unpinned for this path
+(see oracle/edm_ref.py)."""
+import pytest
 import torch
 
 from diffusionmodelscustom_amd.elucidated_imagen import ElucidatedImagen, GaussianDiffusionContinuousTimes
@@ -34,58 +36,51 @@ def test_spelled_out_quantile_is_torch_quantile():
             assert torch.equal(edm_ref.quantile_by_sorting(rows, q), torch.quantile(rows, q, dim=-1)), (n, q)
 
 
-def run_pair(model, shape, **kw):
-    tape = Tape(7)
-    model.noise_source = tape
-    got = model.one_unet_sample(model.unets[0], shape, unet_number=1, **kw)
-    n_draws = tape.cursor
-    tape.rewind()
-    unet = model.unets[0]
-    okw = dict(kw)
-    dyn = okw.pop("dynamic_threshold", True)
-    want, _ = edm_ref.one_unet_sample(unet.forward_with_cond_scale, shape, model.hparams[0], tape, self_cond_net=unet.self_cond,
-                                      dynamic_threshold=dyn, percentile=model.dynamic_thresholding_percentile,
-                                      cond_scale=1., **okw)
-    assert tape.cursor == n_draws
-    return got, want
-
-
-def test_cpu_path_equals_the_oracle():
+def test_sampling_on_a_cpu_device_is_refused():
     model = make()
-    for dyn in (True, False):
-        got, want = run_pair(model, (2, 3, 8, 8), dynamic_threshold=dyn)
-        assert torch.equal(got, want)
-    got, want = run_pair(model, (2, 3, 8, 8), clamp=False, skip_steps=2, sigma_max=20.)
-    assert torch.equal(got, want)
+    model.noise_source = Tape(7)
+    with pytest.raises(NotImplementedError, match="CUDA device"):
+        model.one_unet_sample(model.unets[0], (2, 3, 8, 8), unet_number=1)
+    with pytest.raises(NotImplementedError, match="CUDA float32"):
+        model.threshold_x_start(torch.randn(2, 3, 8, 8))
+    with pytest.raises(NotImplementedError, match="CUDA float32"):
+        model.preconditioned_network_forward(model.unets[0].forward_with_cond_scale, torch.randn(2, 3, 8, 8), 1.5,
+                                             sigma_data=0.5)
+    assert torch.equal(model.threshold_x_start(torch.full((1, 1, 2, 2), 3.0), False), torch.ones(1, 1, 2, 2))
 
 
-def test_cpu_inpainting_equals_the_oracle():
+def test_a_call_with_supplied_draws_leaves_the_default_generator_alone():
+    """The Philox seed of a call is drawn from torch's generator only when a kernel needs it."""
+    from diffusionmodelscustom_amd.elucidated_imagen import _Draws
     model = make()
-    torch.manual_seed(1)
-    inpaint = torch.rand(2, 3, 8, 8)
-    masks = torch.rand(2, 8, 8) > 0.5
-    got, want = run_pair(model, (2, 3, 8, 8), inpaint_images=inpaint, inpaint_masks=masks, inpaint_resample_times=2)
-    assert torch.equal(got, want)
-    keep = masks.unsqueeze(1).expand_as(got)
-    assert torch.allclose(got[keep], inpaint[keep], atol=1e-6)  # the masked pixels come back as they were given
+    torch.manual_seed(5)
+    before = torch.get_rng_state()
+    model.noise_source = Tape(1)
+    d = _Draws(model, torch.device("cpu"))
+    d.normal((2, 3))
+    assert torch.equal(torch.get_rng_state(), before)
+    model.noise_source = None
+    d = _Draws(model, torch.device("cpu"))
+    assert torch.equal(torch.get_rng_state(), before)
+    first = d.kernel_args((2, 3))
+    assert not torch.equal(torch.get_rng_state(), before)
+    assert d.kernel_args((2, 3))["seed"] == first["seed"] and d.kernel_args((2, 3))["offset"] == 3
 
 
-def test_cascade_feeds_the_noised_upsampled_stage_to_the_next():
+def test_oracle_cascade_feeds_the_noised_upsampled_stage_to_the_next():
     model = make(2)
     tape = Tape(3)
-    model.noise_source = tape
-    outs = model.sample(batch_size=2, return_all_unet_outputs=True)
+    nets = [u.forward_with_cond_scale for u in model.unets]
+    outs = edm_ref.cascade_sample(nets, [8, 16], model.hparams, tape, batch_size=2, self_cond=(True, False))
     assert [tuple(o.shape) for o in outs] == [(2, 3, 8, 8), (2, 3, 16, 16)]
-    # the same by hand from the oracle's pieces
     tape.rewind()
-    first, _ = edm_ref.one_unet_sample(model.unets[0].forward_with_cond_scale, (2, 3, 8, 8), model.hparams[0], tape,
-                                       self_cond_net=True, cond_scale=1.)
+    first, _ = edm_ref.one_unet_sample(nets[0], (2, 3, 8, 8), model.hparams[0], tape, self_cond_net=True, cond_scale=1.)
     assert torch.equal(outs[0], first)
     up = torch.nn.functional.interpolate(first, 16, mode="nearest") * 2. - 1.
     times = torch.full((2,), 0.2)
     low = edm_ref.lowres_q_sample(up, times, tape((2, 3, 16, 16)))
-    second, _ = edm_ref.one_unet_sample(model.unets[1].forward_with_cond_scale, (2, 3, 16, 16), model.hparams[1], tape,
-                                        cond_scale=1., lowres_cond_img=low, lowres_noise_times=times)
+    second, _ = edm_ref.one_unet_sample(nets[1], (2, 3, 16, 16), model.hparams[1], tape, cond_scale=1., lowres_cond_img=low,
+                                        lowres_noise_times=times)
     assert torch.equal(outs[1], second)
 
 

@@ -176,7 +176,7 @@ def test_one_unet_sample_equals_the_oracle(case):
         assert torch.equal(got, want)
 
 
-def test_cascade_on_the_gpu_matches_the_cpu_path():
+def test_cascade_on_the_gpu_matches_the_oracle():
     model = make(2)
     tape = Tape(13)
     model.noise_source = tape
@@ -184,13 +184,30 @@ def test_cascade_on_the_gpu_matches_the_cpu_path():
     n_draws = tape.cursor
     tape.rewind()
     cpu_model = make(2).cpu()
-    cpu_model.noise_source = tape
-    wants = cpu_model.sample(batch_size=2, return_all_unet_outputs=True)
+    wants = edm_ref.cascade_sample([u.forward_with_cond_scale for u in cpu_model.unets], [16, 32], cpu_model.hparams, tape,
+                                   batch_size=2, self_cond=(True, False),
+                                   percentile=cpu_model.dynamic_thresholding_percentile)
     assert tape.cursor == n_draws
     assert [tuple(o.shape) for o in outs] == [(2, 3, 16, 16), (2, 3, 32, 32)]
     assert torch.allclose(outs[0], wants[0], rtol=0, atol=2e-6)
     # the low-resolution conditioning image is noised with device transcendentals (log, expm1, sigmoid)
     assert torch.allclose(outs[1], wants[1], rtol=0, atol=1e-5)
+
+
+def test_preconditioned_forward_equals_the_oracle():
+    model = make()
+    torch.manual_seed(3)
+    x = torch.randn(3, 3, 16, 16)
+    cpu_net = ToyUnet().forward_with_cond_scale
+    for clamp, dyn in ((False, True), (True, False), (True, True)):
+        want = edm_ref.preconditioned_network_forward(cpu_net, x, 2.5, sigma_data=0.5, clamp=clamp, dynamic_threshold=dyn,
+                                                      percentile=model.dynamic_thresholding_percentile, cond_scale=1.)
+        got = model.preconditioned_network_forward(model.unets[0].forward_with_cond_scale, x.to(DEV), 2.5, sigma_data=0.5,
+                                                   clamp=clamp, dynamic_threshold=dyn, cond_scale=1.).cpu()
+        assert torch.allclose(got, want, rtol=0, atol=2e-6), (clamp, dyn)
+    with pytest.raises(NotImplementedError, match="one noise level"):
+        model.preconditioned_network_forward(model.unets[0].forward_with_cond_scale, x.to(DEV),
+                                             torch.tensor([1.0, 2.0, 3.0], device=DEV), sigma_data=0.5)
 
 
 def test_in_kernel_noise_is_standard_normal_and_seeded():

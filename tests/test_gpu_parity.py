@@ -150,6 +150,19 @@ def test_attention_softmax_is_stable_for_large_logits(cond64, dev):
     assert rel_err(out, want) < TOL_OP
 
 
+@pytest.mark.parametrize("index,C,side", [(0, 64, 32), (1, 64, 16), (2, 128, 8), (3, 256, 4), (4, 512, 2)])
+def test_attention_propagates_nan_like_torch(cond64, dev, index, C, side):
+    """A NaN anywhere in an image's input reaches every output of that image's attention block (LayerNorm spreads it
+    over the token, the token's key over every query, as torch's modules:100-107 do), and no other image."""
+    _, _, ops = cond64
+    x = gs.randn(600 + index, 3, C, side, side)
+    clean_out = ops.attention(index, x.to(dev)).cpu()
+    x[1, C // 3, side // 2, side - 1] = float("nan")
+    out = ops.attention(index, x.to(dev)).cpu()
+    assert torch.isnan(out[1]).all(), f"{int((~torch.isnan(out[1])).sum())} values of the poisoned image are not NaN"
+    assert torch.equal(out[0], clean_out[0]) and torch.equal(out[2], clean_out[2])
+
+
 def test_stem_convs(cond64, golden, dev):
     _, _, ops = cond64
     g = golden("per_op")
@@ -461,7 +474,8 @@ def conv2_reference(sd, x):
     return torch.relu(y)
 
 
-@pytest.mark.parametrize("case", ["plain", "huge_value", "non_finite_free_huge_region", "tiny", "tiny_with_zeros", "zeros"])
+@pytest.mark.parametrize("case", ["plain", "huge_value", "non_finite_free_huge_region", "tiny", "tiny_with_zeros", "zeros",
+                                  "band_gaussian_3e-3", "band_uniform_2^-8_2^-3", "band_mixed_with_order_one"])
 def test_split_operand_convolution_value_ranges(cond64, dev, case):
     """The convolutions multiply on the fp16 matrix cores with both operands split in two fp16 halves while a
     workgroup's staged activations stay below 2^15 and are not uniformly tiny; a workgroup that meets anything else
@@ -480,6 +494,17 @@ def test_split_operand_convolution_value_ranges(cond64, dev, case):
         x[:, :, ::2] = 0.0
     elif case == "zeros":
         x[0] = 0.0
+    elif case == "band_gaussian_3e-3":
+        # the band in which the split path is still taken (a tile's largest value is above 2^-8) while the low halves
+        # are fp16 subnormals: values are kept to an absolute 2^-25, i.e. to 2^-17 relative at the band's lower end
+        x *= 3.0e-3
+    elif case == "band_uniform_2^-8_2^-3":
+        g = torch.Generator().manual_seed(43)
+        mag = torch.exp2(torch.rand(x.shape, generator=g) * 5.0 - 8.0)  # log-uniform in [2^-8, 2^-3)
+        x = mag * torch.sign(x)
+    elif case == "band_mixed_with_order_one":
+        # every tile holds order-one values (so no tile falls back) beside channels that sit deep in the band
+        x[:, ::2] *= 4.0e-3
     want = conv2_reference(sd, x)
     got = ops.conv2_bn_relu(x.to(dev)).cpu().double()
     assert torch.isfinite(got).all()

@@ -182,3 +182,24 @@ def test_full_batch_equals_single_image_evaluations(clean, dev, variant):
             one = model(inp["x"][i:i + 1], t[i:i + 1], pick(inp["y"], i), pick(inp["cond_img"], i),
                         pick(inp["lsm_cond"], i), pick(inp["topo_cond"], i))
             assert rel_err(full[i:i + 1].cpu(), one.cpu()) < TOL_OP, i
+
+
+def test_data_scaled_forward_at_batch_64(clean, dev):
+    """One evaluation of the conditional network at the benchmark's batch on inputs as a `data_scaled` run feeds them
+    (images and conditioning fields scaled to [0, 1], the state a few shrunk-noise steps away from its start): the
+    activations of the first levels then sit well below one, in the band where the split operands' low halves are
+    fp16 subnormals.  Against the CPU restatement, per image."""
+    model, sd = clean["clean_cond"][0], clean["clean_cond"][1]
+    B = 64
+    g = torch.Generator().manual_seed(77)
+    x = 0.05 * torch.randn(B, 1, 64, 64, generator=g)
+    cond = torch.rand(B, 1, 64, 64, generator=g)
+    lsm = (torch.rand(B, 1, 64, 64, generator=g) < 0.45).float()
+    topo = torch.rand(B, 1, 64, 64, generator=g)
+    y = torch.randint(0, 4, (B,), generator=g)
+    t = torch.randint(1, 1000, (B,), generator=g)
+    with torch.no_grad():
+        got = model(x.to(dev), t.to(dev), y.to(dev), cond.to(dev), lsm.to(dev), topo.to(dev)).cpu()
+        want = cpu_ref.unet_forward(sd, x, t, y, cond, lsm, topo, clean=True)
+    for b in range(B):
+        assert rel_err(got[b], want[b]) < TOL_FWD, f"image {b}"

@@ -74,7 +74,8 @@ def test_core_forward_and_backward_match_float64(B, heads, L, qscale):
 
 
 @pytest.mark.parametrize("case", ["huge_values_late", "huge_values_first_tile", "tiny_values", "wide_probability_range",
-                                  "nonfinite_value", "huge_keys_late", "huge_queries", "tiny_keys_large_queries"])
+                                  "nonfinite_value", "huge_keys_late", "huge_queries", "tiny_keys_large_queries",
+                                  "band_values_3e-3", "band_all_uniform_2^-8_2^-3"])
 def test_core_forward_value_ranges(case):
     """The forward kernel multiplies K Q^T and P V on the fp16 matrix cores (operands split in fp16 halves) while every
     |K|, |V| it has staged and every scaled |Q| of the workgroup is below 2^15, and in fp32 from the first tile on that
@@ -104,6 +105,12 @@ def test_core_forward_value_ranges(case):
     elif case == "tiny_keys_large_queries":
         k *= 1e-3                        # low halves and the 2^-11 copies of K deep in the fp16 subnormals
         q *= 300.0
+    elif case == "band_values_3e-3":
+        v *= 3e-3                        # split path taken, low halves of V small: relative error, not absolute, must hold
+    elif case == "band_all_uniform_2^-8_2^-3":
+        def band(t):
+            return torch.exp2(torch.rand(t.shape, generator=g) * 5.0 - 8.0) * torch.sign(t)
+        q, k, v = band(q) * 64.0, band(k), band(v)   # scores of order one from keys in the band
     dout = torch.zeros(B, L, heads * 16)
     out, _, _, _, lse2 = run_core(q, k, v, dout)
     p = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 4.0, dim=-1)

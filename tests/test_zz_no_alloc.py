@@ -66,3 +66,43 @@ def test_no_alloc_instance_norm_refuses_what_does_not_fit():
     assert lib.danra_instance_norm_noalloc(None, _ptr(x), 1, 4, 32, _stream()) == -1    # null input
     assert lib.danra_instance_norm_noalloc(_ptr(x), _ptr(x), 1, 4, 48, _stream()) == -1  # C not a multiple of 32
     assert lib.danra_instance_norm_noalloc(_ptr(x), _ptr(x), 0, 4, 32, _stream()) == -1  # empty batch
+
+
+def test_no_alloc_entry_point_allocates_nothing_and_runs_under_graph_capture():
+    """What the entry point exists for: the device's free memory does not move across its calls, and it can be captured
+    into a graph (an allocating call cannot); the replay equals the allocating entry point bit for bit."""
+    lib = hip_engine.load_library()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((4, 64, 64, 64), generator=g).to(DEV)      # sliced statistics: every region of the scratch in use
+    y = torch.empty_like(x)
+    want = torch.empty_like(x)
+    B, H, W, C = x.shape
+    assert lib.danra_instance_norm(_ptr(x), _ptr(want), B, H * W, C, _stream()) == 0
+    assert lib.danra_instance_norm_noalloc(_ptr(x), _ptr(y), B, H * W, C, _stream()) == 0   # warm call: scratch resolved
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        assert lib.danra_instance_norm_noalloc(_ptr(x), _ptr(y), B, H * W, C, _stream()) == 0
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, f"free device memory moved by {free_before - free_after} bytes"
+    assert torch.equal(y, want)
+
+    y.fill_(float("nan"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = lib.danra_instance_norm_noalloc(_ptr(x), _ptr(y), B, H * W, C, ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0, lib.danra_last_error()
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.isnan(y).all(), "capture must not execute the kernels"
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    x.mul_(0.5).add_(1.0)                                          # new input, same buffers: replay again
+    assert lib.danra_instance_norm(_ptr(x), _ptr(want), B, H * W, C, _stream()) == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)

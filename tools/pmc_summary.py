@@ -1,7 +1,7 @@
-"""Summarise the two counter passes of tools/pmc_traffic.sh into the table kept as profiles/r02_pmc_traffic.txt and the
-per-family averages that bench.py quotes as roofline.traffic, kept as profiles/r02_family_traffic.json.
+"""Summarise the two counter passes of tools/pmc_traffic.sh into the table kept as profiles/rNN_pmc_traffic.txt and the
+per-family averages that bench.py quotes as roofline.traffic, kept as profiles/rNN_family_traffic.json.
 
-    python tools/pmc_summary.py gpurun_out/pmc profiles/r02_family_traffic.json > profiles/r02_pmc_traffic.txt
+    python tools/pmc_summary.py gpurun_out/pmc profiles/rNN_family_traffic.json > profiles/rNN_pmc_traffic.txt
 
 Counter unit: KiB.  gfx950 correction: FETCH_SIZE counts a 128-byte read request as 64 bytes, so reads = 2 x FETCH_SIZE;
 WRITE_SIZE is exact.  Median over the launches of each (kernel, grid size)."""
@@ -62,6 +62,11 @@ def main():
         if flash:
             grids = sorted(flash, reverse=True)  # larger grid = L 1024, smaller = L 256 (batch 64, 4 heads)
             out["k_flash_hd16"] = {"L1024_B64": flash[grids[0]], "L256_B64": flash[grids[-1]]}
+        # the build these counters belong to: bench.py quotes the figures only while it runs this very library
+        import hashlib
+        lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusionmodelscustom_amd", "libdanra_hip.so")
+        with open(lib, "rb") as fh:
+            out["library_sha256"] = hashlib.sha256(fh.read()).hexdigest()
         with open(sys.argv[2], "w") as fh:
             json.dump(out, fh, indent=1)
 
