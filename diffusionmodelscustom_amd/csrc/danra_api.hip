@@ -58,6 +58,7 @@ struct SplitW {
 
 struct ConvP {
     SplitW split;
+    float* wfrag = nullptr; // 3x3 stride-1 convolutions: the split weights in the fragment order of k_conv_win, or null
     float* w = nullptr;     // [Cout][KH][KW][Cin] (stem: [Cout][Cin][KH][KW])
     float* bias = nullptr;  // folded BatchNorm shift or conv bias (may be null)
     int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
@@ -110,7 +111,8 @@ struct Workspace {
     int64_t* ys;
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
-    int step_exec_mode = -1;  // what the captured step was built for: bit 0 = labels, bit 1 = guided (two evaluations)
+    int step_exec_mode = -1;  // what the captured step was built for: bit 0 = labels, bit 1 = guided (two evaluations),
+                              // bit 2 = every product with fp32 instructions (danra_set_fp32_products)
 };
 constexpr int kMaxTimesteps = 8192;  // rows of the coefficient table
 
@@ -136,6 +138,8 @@ struct danra_handle_s {
     float *final_wt = nullptr, *final_bt = nullptr;
     // DANRA_FUSED_SMALL_ATTENTION=0 keeps the three-kernel form of the short-sequence attention blocks (comparison runs)
     bool fused_small_attention = !(getenv("DANRA_FUSED_SMALL_ATTENTION") && atoi(getenv("DANRA_FUSED_SMALL_ATTENTION")) == 0);
+    // DANRA_CONV_WIN=0: every convolution through the implicit-GEMM kernel (comparison runs)
+    bool conv_win = !(getenv("DANRA_CONV_WIN") && atoi(getenv("DANRA_CONV_WIN")) == 0);
     SplitW final_s_wt;
     float *tw = nullptr, *tb = nullptr;  // time projections [tb_width][dim], [tb_width]
     float* label_emb = nullptr;
@@ -295,6 +299,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         c.w = bp.take((size_t)Cout * Cin * k * k);
         c.bias = bp.take(Cout);
         if (Cin % 64 == 0) want_split(c.split, c.w, Cout, (size_t)Cin * k * k);
+        c.wfrag = (k == 3 && stride == 1 && Cin % 64 == 0 && Cout % 32 == 0) ? bh.take((size_t)Cout * Cin * 9) : nullptr;
         if (fill) {
             // scratch_scale is reused by consecutive launches on one stream: ordered, no hazard
             HIP_TRY(launch_bn_fold(src_of(h, bn + ".weight"), src_of(h, bn + ".bias"), src_of(h, bn + ".running_mean"),
@@ -433,6 +438,7 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         want_split(d.s_wt, d.wt, (size_t)4 * d.Cin, d.Cin, true);
         d.wt_frag = d.Cin == 64 ? bh.take((size_t)4 * d.Cin * d.Cin) : nullptr;
         want_split(d.conv.split, d.conv.w, d.Cout, (size_t)9 * d.Cin);
+        d.conv.wfrag = (d.Cin % 64 == 0 && d.Cout % 32 == 0) ? bh.take((size_t)d.Cout * d.Cin * 9) : nullptr;
         if (fill) {
             HIP_TRY(launch_pack_convT(src_of(h, p + ".transpose.weight"), src_of(h, p + ".transpose.bias"), d.wt, d.bt,
                                       d.Cin, d.Cin, st));
@@ -595,6 +601,7 @@ void choose_split(IGemmArgs& a, const Workspace& ws) {
 }
 
 int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st);
+int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st);
 
 void use_split(IGemmArgs& a, const SplitW& s) {
     a.Wh = s.wh;
@@ -632,6 +639,19 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
     a.pix_major = (c.KH > 1 && Ho * Wo <= 64) ? 1 : 0;
     a.batch = B;
     if (c.Cin % 32 || c.Cout % 64) return fail(DANRA_EINVAL, "conv channels %d->%d unsupported", c.Cin, c.Cout);
+    // 3x3 stride-1 convolutions on maps with power-of-two sides: the kernel that stages the input window in LDS and
+    // streams the weights in fragment order (never split over workgroups, so it leaves no slabs)
+    if (c.wfrag && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && !out2 && h->conv_win && !igemm_fp32_products_forced() &&
+        conv_win_supported(B, Hi, Wi, c.Cin, c.Cout, nmean != nullptr)) {
+        ConvWinArgs w;
+        memset(&w, 0, sizeof(w));
+        w.x = in; w.wf = c.wfrag; w.w32 = c.w; w.wscale = c.split.inv_scale; w.bias = c.bias; w.res = res; w.tbias = tbias;
+        w.nmean = nmean; w.nrstd = nrstd; w.out = out;
+        w.B = B; w.H = Hi; w.W = Wi; w.Cin = c.Cin; w.Cout = c.Cout; w.act = a.act; w.tb_stride = h->tb_width;
+        if (slabs) slabs->count = 0;
+        return conv_win(h, w, 2.0 * (double)a.M * (double)a.N * (double)a.K,
+                        4.0 * ((double)a.N * a.K + (double)a.M * a.N * (res ? 2.0 : 1.0) + (double)B * Hi * Wi * c.Cin), st);
+    }
     choose_split(a, h->ws);
     if (slabs) {
         slabs->count = 0;
@@ -733,6 +753,22 @@ int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
         else if (a.a_mode == A_CONV) elems += (double)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi * a.Cin;
         else elems += (double)(a.M / (a.Ho * a.Wo)) * a.Hi * a.Wi * (a.K / 64);  // stem: K = planes x 8 x 8
         h->prof_bytes += 4.0 * elems;
+    }
+    return DANRA_OK;
+}
+
+// The window-staged 3x3 convolutions belong to the same timed family (every product of theirs is a split-operand one).
+int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st) {
+    const bool timed = h->prof_kind == DANRA_PROF_IGEMM && h->prof_now;
+    {
+        ProfScope scope(h, timed);
+        HIP_TRY(launch_conv_win(w, st));
+    }
+    if (timed) {
+        h->prof_flops += flops;
+        h->prof_exec_flops += 3.0 * flops;
+        h->prof_split_flops += flops;
+        h->prof_bytes += bytes;
     }
     return DANRA_OK;
 }
@@ -1154,6 +1190,16 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
     RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
     for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
+    {   // the 3x3 stride-1 convolutions' weights in the fragment order of k_conv_win, with the scale of their split copy
+        auto frag = [&](ConvP& c) -> int {
+            if (c.wfrag && !c.split.wh) c.wfrag = nullptr;
+            if (c.wfrag) HIP_TRY(launch_pack_conv_frag(c.w, c.wfrag, c.Cout, c.Cin, 1.0f / c.split.inv_scale, st));
+            return DANRA_OK;
+        };
+        for (auto& layer : h->blocks)
+            for (BlockP& blk : layer) { RC_TRY(frag(blk.c1)); RC_TRY(frag(blk.c2)); }
+        for (DecP& d : h->dec) RC_TRY(frag(d.conv));
+    }
     for (DecP& d : h->dec) {
         if (d.wt_frag && !d.s_wt.wh) d.wt_frag = nullptr;
         if (d.wt_frag) HIP_TRY(launch_frag16_from_f32(d.wt, d.wt_frag, 4 * d.Cin, d.Cin, 1.0f / d.s_wt.inv_scale, st));
@@ -1601,7 +1647,7 @@ int danra_sample_guided(danra_handle_t h, float* x, const int64_t* y, const floa
     // 64th 0.1 %).
     constexpr int kProfStride = 64;
     const bool use_graph = h->graph_mode != 0;
-    const int step_mode = (has_y ? 1 : 0) | (guided ? 2 : 0);
+    const int step_mode = (has_y ? 1 : 0) | (guided ? 2 : 0) | (igemm_fp32_products_forced() ? 4 : 0);
     if (use_graph && (!ws.step_exec || ws.step_exec_mode != step_mode)) {
         h->prof_now = false;
         drop_step_graph(ws);

@@ -338,6 +338,32 @@ hipError_t launch_maxabs(const float* w, size_t n, float* out, hipStream_t strea
 // n float-sized slots; every 64 consecutive weights w become [64 halves hi | 64 halves lo] of scale * w with
 // hi = fp16(scale*w) (rounded towards zero) and lo = fp16(scale*w - hi).  `scale` is a power of two.
 hipError_t launch_split_weights(const float* w, float* out, size_t n, float scale, hipStream_t stream, bool frag64 = false);
+
+// ---------------------------------------------------------------- 3x3 stride-1 convolutions with the input window in LDS
+// out[b][y][x][n] = epilogue( sum_{kh, kw, c} x[b][y + kh - 1][x + kw - 1][c] * w[n][kh][kw][c] ), NHWC fp32, zero padding,
+// as split-operand fp16 products (kernels_conv_win.hip).  epilogue as k_igemm's: + bias[n]; + res[row][n]; activation;
+// + tbias[b * tb_stride + n].  nmean / nrstd ([B][Cin], both or neither): InstanceNorm of the input applied on load.
+struct ConvWinArgs {
+    const float* x;
+    const void* wf;      // the weights in fragment order (launch_pack_conv_frag), scaled by 1 / wscale
+    const float* w32;    // the same weights as fp32 [Cout][3][3][Cin]: what a tile out of the split's range multiplies with
+    float wscale;
+    const float* bias;
+    const float* res;
+    const float* tbias;
+    const float* nmean;
+    const float* nrstd;
+    float* out;
+    int B, H, W, Cin, Cout;
+    int act, tb_stride;
+    // filled in by launch_conv_win
+    int sh_w, sh_hw, lds_img, lds_window, lds_bufs;
+};
+// H, W powers of two (W <= 64), Cin % 64 == 0, Cout % 32 == 0 and a tile shape that fits: otherwise the caller uses launch_igemm
+bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm);
+hipError_t launch_conv_win(const ConvWinArgs& a, hipStream_t stream);
+// w [Cout][3][3][Cin] fp32 -> out (same number of bytes): scale * w split in fp16 halves, in k_conv_win's fragment order
+hipError_t launch_pack_conv_frag(const float* w, float* out, int Cout, int Cin, float scale, hipStream_t stream);
 hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                           float* scale, float* shift, int C, hipStream_t stream);
 hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_ohwi, int O, int I, int KH, int KW,

@@ -578,6 +578,31 @@ def test_split_operand_forward_equals_fp32_products(cond64, golden, dev):
     assert not torch.equal(outs[0], outs[1]), "the switch changed nothing: the split-operand form did not run"
 
 
+def test_fp32_products_switch_reaches_a_step_that_was_already_captured(cond64, dev):
+    """sample() replays a captured denoise step; flipping danra_set_fp32_products between two calls of the same shape
+    must rebuild it (a replay of the old capture would run the other form's kernels)."""
+    from diffusionmodelscustom_amd import DiffusionUtils
+    model, _, ops = cond64
+    B, T = 2, 5
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64).items()}
+    noise = torch.randn(T - 2, B, 1, 64, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+    du = DiffusionUtils(T, gs.BETA_MIN, gs.BETA_MAX, dev, "linear")
+
+    def run():
+        return du.sample_with_host_noise(inp["x"], model, noise, inp["y"], cond_img=inp["cond_img"],
+                                         lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"]).cpu()
+    split = run()
+    try:
+        ops.lib.danra_set_fp32_products(1)
+        strict = run()
+    finally:
+        ops.lib.danra_set_fp32_products(0)
+    again = run()
+    assert torch.equal(split, again)
+    assert not torch.equal(split, strict), "the captured split-operand step was replayed under the fp32 switch"
+    assert rel_err(split, strict) < 1e-4
+
+
 def test_split_operand_k64_chain_falls_back_on_large_activations(cond64, dev):
     """Batch 32 puts the last decoder block's attention tail and the final transposed convolution into one kernel whose
     products are split-operand fp16 products; conditioning planes scaled by 3e5 drive the skip connection it adds - and
