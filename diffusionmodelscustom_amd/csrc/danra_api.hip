@@ -1904,6 +1904,41 @@ int danra_instance_norm_noalloc(const float* x, float* out, int B, int HW, int C
     return DANRA_OK;
 }
 
+// A 3x3 stride-1 convolution through the window-staged kernel, for unit tests of that kernel on shapes and value
+// ranges of the caller's choosing: packs the weights (scale from their largest magnitude, fragment order) into a
+// temporary buffer, runs the kernel and waits for it.
+int danra_conv3x3(const float* x, const float* w, const float* bias, const float* res, const float* nmean, const float* nrstd,
+                  float* out, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    if (!x || !w || !out) return fail(DANRA_EINVAL, "null argument");
+    if ((nmean == nullptr) != (nrstd == nullptr)) return fail(DANRA_EINVAL, "nmean and nrstd come together");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DANRA_EINVAL, "sizes must be positive");
+    if (!conv_win_supported(B, H, W, Cin, Cout, nmean != nullptr))
+        return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d%s: not a shape of the window-staged kernel (sides powers of two up to 64 "
+                    "wide, Cin %% 64 == 0, Cout %% 32 == 0)", B, H, W, Cin, Cout, nmean ? " with norm on load" : "");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)Cout * 9 * Cin;
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, (n + 64) * sizeof(float)) != hipSuccess) return fail(DANRA_ENOMEM, "temporary weight buffer");
+    auto done = [&](int rc) { (void)hipFree(tmp); return rc; };
+    float mx = 0.f;
+    if (launch_maxabs(w, n, tmp + n, st) != hipSuccess || hipMemcpyAsync(&mx, tmp + n, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return done(fail(DANRA_EHIP, "weight maximum: %s", hipGetErrorString(hipGetLastError())));
+    if (!(mx > 0.f) || !(mx <= 3.0e38f)) return done(fail(DANRA_EINVAL, "the weights are all zero or not finite: no split form"));
+    int e = 0;
+    (void)frexpf(mx, &e);
+    const int sft = 13 - e;   // 2^sft * mx in [2^12, 2^13), as the packed model's matrices are scaled
+    if (launch_pack_conv_frag(w, tmp, Cout, Cin, ldexpf(1.0f, sft), st) != hipSuccess) return done(fail(DANRA_EHIP, "weight packing failed"));
+    ConvWinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wf = tmp; a.w32 = w; a.wscale = ldexpf(1.0f, -sft); a.bias = bias; a.res = res; a.nmean = nmean; a.nrstd = nrstd; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = relu ? ACT_RELU : ACT_NONE;
+    const hipError_t le = launch_conv_win(a, st);
+    const hipError_t se = hipStreamSynchronize(st);
+    if (le != hipSuccess || se != hipSuccess) return done(fail(DANRA_EHIP, "window convolution: %s", hipGetErrorString(le != hipSuccess ? le : se)));
+    return done(DANRA_OK);
+}
+
 int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream) {
     RC_TRY(op_args(src, dst, B, HW));
     if (C <= 0) return fail(DANRA_EINVAL, "C must be positive");

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     auto row_of = [&](int q, int& img) -> int {   // row of the output tensor of tile pixel q, or -1
         if (PIXM) { img = b0 + q; return img * HW + pos; }
         const int m = tile * TP + q;
-        img = m >> p.sh_hw;
+        img = min(m >> p.sh_hw, p.B - 1);          // (rows past the batch in a ragged last tile: never stored)
         return m < M ? m : -1;
     };
     int erow[NROWS], eimg[NROWS];

@@ -347,6 +347,14 @@ int danra_resnet_layer(danra_handle_t h, int level, const float* x_nhwc, float* 
  * fmap NHWC [B][H][W][Cin] -> out NHWC [B][2H][2W][Cout]; t_dev int64[B]. */
 int danra_decoder_block(danra_handle_t h, int block, const float* fmap_nhwc, const float* skip_nhwc,
                         const int64_t* t_dev, float* out_nhwc, int B, int H, int W, void* stream);
+/* One 3x3 stride-1 padding-1 convolution as the BasicBlocks (torchvision resnet.BasicBlock under modules:276-303) and
+ * the DecoderBlocks (modules:415-416, 437) apply it, through the window-staged kernel, for unit tests: NHWC x
+ * [B][H][W][Cin], w [Cout][3][3][Cin] (OIHW permuted to taps-then-channels), optional bias [Cout], residual (NHWC, added
+ * before the optional ReLU) and InstanceNorm of the input on load (nmean, nrstd [B][Cin]: (x - mean) * rstd, zero
+ * padding applied after it, as modules:436-437 compose them).  H, W powers of two (W <= 64), Cin % 64 == 0,
+ * Cout % 32 == 0.  Allocates a temporary copy of the weights and waits for the stream. */
+int danra_conv3x3(const float* x_nhwc, const float* w, const float* bias, const float* res_nhwc, const float* nmean,
+                  const float* nrstd, float* out_nhwc, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
 /* InstanceNorm2d(affine=False, eps=1e-5) (modules:412,419) on NHWC. */
 int danra_instance_norm(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
 /* danra_instance_norm for callers that cannot allocate device memory (code under hipGraph capture, serving loops,

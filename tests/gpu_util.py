@@ -109,3 +109,17 @@ class Ops:
                                                            ctypes.c_uint64(step), _stream()),
                "danra_ddpm_update_philox")
         return x
+
+
+def conv3x3(lib, x, w, bias=None, res=None, norm=None, relu=False):
+    """danra_conv3x3 on NCHW tensors: x [B, Cin, H, W], w [Cout, Cin, 3, 3] (torch layout), norm = (mean, rstd) [B, Cin]."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xin = to_nhwc(lib, x)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    rin = None if res is None else to_nhwc(lib, res)
+    out = torch.empty((B, H, W, Cout), device=x.device, dtype=torch.float32)
+    mean, rstd = (None, None) if norm is None else (norm[0].contiguous(), norm[1].contiguous())
+    _check(lib, lib.danra_conv3x3(_ptr(xin), _ptr(wp), _ptr(bias), _ptr(rin), _ptr(mean), _ptr(rstd), _ptr(out), B, H, W, Cin,
+                                  Cout, int(relu), _stream()), "danra_conv3x3")
+    return to_nchw(lib, out)
