@@ -58,7 +58,7 @@ struct SplitW {
 
 struct ConvP {
     SplitW split;
-    float* wfrag = nullptr; // 3x3 stride-1 convolutions: the split weights in the fragment order of k_conv_win, or null
+    float* wfrag = nullptr; // 3x3 stride-1 and 8x8 stride-2 convolutions: the split weights in the fragment order of the window kernels, or null
     float* w = nullptr;     // [Cout][KH][KW][Cin] (stem: [Cout][Cin][KH][KW])
     float* bias = nullptr;  // folded BatchNorm shift or conv bias (may be null)
     int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
@@ -140,6 +140,7 @@ struct danra_handle_s {
     bool fused_small_attention = !(getenv("DANRA_FUSED_SMALL_ATTENTION") && atoi(getenv("DANRA_FUSED_SMALL_ATTENTION")) == 0);
     // DANRA_CONV_WIN=0: every convolution through the implicit-GEMM kernel (comparison runs)
     bool conv_win = !(getenv("DANRA_CONV_WIN") && atoi(getenv("DANRA_CONV_WIN")) == 0);
+    bool conv_s2 = !(getenv("DANRA_CONV_S2") && atoi(getenv("DANRA_CONV_S2")) == 0);   // ... only the 8x8 stride-2 one
     SplitW final_s_wt;
     float *tw = nullptr, *tb = nullptr;  // time projections [tb_width][dim], [tb_width]
     float* label_emb = nullptr;
@@ -299,7 +300,8 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
         c.w = bp.take((size_t)Cout * Cin * k * k);
         c.bias = bp.take(Cout);
         if (Cin % 64 == 0) want_split(c.split, c.w, Cout, (size_t)Cin * k * k);
-        c.wfrag = (k == 3 && stride == 1 && Cin % 64 == 0 && Cout % 32 == 0) ? bh.take((size_t)Cout * Cin * 9) : nullptr;
+        c.wfrag = ((k == 3 && stride == 1 && Cin % 64 == 0 && Cout % 32 == 0) || (k == 8 && stride == 2 && pad == 3 && Cin % 64 == 0 && Cout % 64 == 0))
+                      ? bh.take((size_t)Cout * Cin * k * k) : nullptr;
         if (fill) {
             // scratch_scale is reused by consecutive launches on one stream: ordered, no hazard
             HIP_TRY(launch_bn_fold(src_of(h, bn + ".weight"), src_of(h, bn + ".bias"), src_of(h, bn + ".running_mean"),
@@ -601,7 +603,7 @@ void choose_split(IGemmArgs& a, const Workspace& ws) {
 }
 
 int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st);
-int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st);
+int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st, bool strided8 = false);
 
 void use_split(IGemmArgs& a, const SplitW& s) {
     a.Wh = s.wh;
@@ -651,6 +653,18 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
         if (slabs) slabs->count = 0;
         return conv_win(h, w, 2.0 * (double)a.M * (double)a.N * (double)a.K,
                         4.0 * ((double)a.N * a.K + (double)a.M * a.N * (res ? 2.0 : 1.0) + (double)B * Hi * Wi * c.Cin), st);
+    }
+    // the 8x8 stride-2 convolution: the strided window kernel
+    if (c.wfrag && c.KH == 8 && c.KW == 8 && c.stride == 2 && c.pad == 3 && !out2 && !nmean && h->conv_win && h->conv_s2 && !igemm_fp32_products_forced() &&
+        conv8s2_supported(B, Hi, Wi, c.Cin, c.Cout)) {
+        ConvWinArgs w;
+        memset(&w, 0, sizeof(w));
+        w.x = in; w.wf = c.wfrag; w.w32 = c.w; w.wscale = c.split.inv_scale; w.bias = c.bias; w.res = res; w.tbias = tbias;
+        w.out = out;
+        w.B = B; w.H = Hi; w.W = Wi; w.Cin = c.Cin; w.Cout = c.Cout; w.act = a.act; w.tb_stride = h->tb_width;
+        if (slabs) slabs->count = 0;
+        return conv_win(h, w, 2.0 * (double)a.M * (double)a.N * (double)a.K,
+                        4.0 * ((double)a.N * a.K + (double)a.M * a.N * (res ? 2.0 : 1.0) + (double)B * Hi * Wi * c.Cin), st, true);
     }
     choose_split(a, h->ws);
     if (slabs) {
@@ -758,11 +772,11 @@ int igemm(danra_handle_s* h, const IGemmArgs& a, hipStream_t st) {
 }
 
 // The window-staged 3x3 convolutions belong to the same timed family (every product of theirs is a split-operand one).
-int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st) {
+int conv_win(danra_handle_s* h, const ConvWinArgs& w, double flops, double bytes, hipStream_t st, bool strided8) {
     const bool timed = h->prof_kind == DANRA_PROF_IGEMM && h->prof_now;
     {
         ProfScope scope(h, timed);
-        HIP_TRY(launch_conv_win(w, st));
+        HIP_TRY(strided8 ? launch_conv8s2(w, st) : launch_conv_win(w, st));
     }
     if (timed) {
         h->prof_flops += flops;
@@ -1190,12 +1204,13 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     RC_TRY(layout_and_pack(h, bp, bh, jobs, true, st));
     RC_TRY(split_registered(h, jobs, (float*)((char*)h->arena_h + bh.off), st));
     for (int k = 0; k < 4; ++k) h->attn[5 + k] = h->dec[k].attn;  // (the copies made during the layout predate the scales)
-    {   // the 3x3 stride-1 convolutions' weights in the fragment order of k_conv_win, with the scale of their split copy
+    {   // the weights of the convolutions that go through the window kernels in fragment order, with the scale of their split copy
         auto frag = [&](ConvP& c) -> int {
             if (c.wfrag && !c.split.wh) c.wfrag = nullptr;
-            if (c.wfrag) HIP_TRY(launch_pack_conv_frag(c.w, c.wfrag, c.Cout, c.Cin, 1.0f / c.split.inv_scale, st));
+            if (c.wfrag) HIP_TRY(launch_pack_conv_frag(c.w, c.wfrag, c.Cout, c.Cin, 1.0f / c.split.inv_scale, st, c.KH * c.KW));
             return DANRA_OK;
         };
+        RC_TRY(frag(h->conv2));
         for (auto& layer : h->blocks)
             for (BlockP& blk : layer) { RC_TRY(frag(blk.c1)); RC_TRY(frag(blk.c2)); }
         for (DecP& d : h->dec) RC_TRY(frag(d.conv));
@@ -1907,16 +1922,10 @@ int danra_instance_norm_noalloc(const float* x, float* out, int B, int HW, int C
 // A 3x3 stride-1 convolution through the window-staged kernel, for unit tests of that kernel on shapes and value
 // ranges of the caller's choosing: packs the weights (scale from their largest magnitude, fragment order) into a
 // temporary buffer, runs the kernel and waits for it.
-int danra_conv3x3(const float* x, const float* w, const float* bias, const float* res, const float* nmean, const float* nrstd,
-                  float* out, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
-    if (!x || !w || !out) return fail(DANRA_EINVAL, "null argument");
-    if ((nmean == nullptr) != (nrstd == nullptr)) return fail(DANRA_EINVAL, "nmean and nrstd come together");
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DANRA_EINVAL, "sizes must be positive");
-    if (!conv_win_supported(B, H, W, Cin, Cout, nmean != nullptr))
-        return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d%s: not a shape of the window-staged kernel (sides powers of two up to 64 "
-                    "wide, Cin %% 64 == 0, Cout %% 32 == 0)", B, H, W, Cin, Cout, nmean ? " with norm on load" : "");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)Cout * 9 * Cin;
+// The per-op entries of the window kernels: scale and pack the weights into a temporary buffer, run, wait.
+static int conv_window_op(int taps, const float* x, const float* w, const float* bias, const float* res, const float* nmean,
+                          const float* nrstd, float* out, int B, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+    const size_t n = (size_t)Cout * taps * Cin;
     float* tmp = nullptr;
     if (hipMalloc((void**)&tmp, (n + 64) * sizeof(float)) != hipSuccess) return fail(DANRA_ENOMEM, "temporary weight buffer");
     auto done = [&](int rc) { (void)hipFree(tmp); return rc; };
@@ -1928,15 +1937,36 @@ int danra_conv3x3(const float* x, const float* w, const float* bias, const float
     int e = 0;
     (void)frexpf(mx, &e);
     const int sft = 13 - e;   // 2^sft * mx in [2^12, 2^13), as the packed model's matrices are scaled
-    if (launch_pack_conv_frag(w, tmp, Cout, Cin, ldexpf(1.0f, sft), st) != hipSuccess) return done(fail(DANRA_EHIP, "weight packing failed"));
+    if (launch_pack_conv_frag(w, tmp, Cout, Cin, ldexpf(1.0f, sft), st, taps) != hipSuccess) return done(fail(DANRA_EHIP, "weight packing failed"));
     ConvWinArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.wf = tmp; a.w32 = w; a.wscale = ldexpf(1.0f, -sft); a.bias = bias; a.res = res; a.nmean = nmean; a.nrstd = nrstd; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = relu ? ACT_RELU : ACT_NONE;
-    const hipError_t le = launch_conv_win(a, st);
+    const hipError_t le = taps == 9 ? launch_conv_win(a, st) : launch_conv8s2(a, st);
     const hipError_t se = hipStreamSynchronize(st);
     if (le != hipSuccess || se != hipSuccess) return done(fail(DANRA_EHIP, "window convolution: %s", hipGetErrorString(le != hipSuccess ? le : se)));
     return done(DANRA_OK);
+}
+
+int danra_conv3x3(const float* x, const float* w, const float* bias, const float* res, const float* nmean, const float* nrstd,
+                  float* out, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    if (!x || !w || !out) return fail(DANRA_EINVAL, "null argument");
+    if ((nmean == nullptr) != (nrstd == nullptr)) return fail(DANRA_EINVAL, "nmean and nrstd come together");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DANRA_EINVAL, "sizes must be positive");
+    if (!conv_win_supported(B, H, W, Cin, Cout, nmean != nullptr))
+        return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d%s: not a shape of the window-staged kernel (sides powers of two up to 64 "
+                    "wide, Cin %% 64 == 0, Cout %% 32 == 0)", B, H, W, Cin, Cout, nmean ? " with norm on load" : "");
+    return conv_window_op(9, x, w, bias, res, nmean, nrstd, out, B, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+int danra_conv8x8s2(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int H, int W, int Cin,
+                    int Cout, int relu, void* stream) {
+    if (!x || !w || !out) return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DANRA_EINVAL, "sizes must be positive");
+    if (!conv8s2_supported(B, H, W, Cin, Cout))
+        return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d: not a shape of the strided window kernel (sides powers of two from 16 on, "
+                    "Cin %% 64 == 0, Cout %% 64 == 0)", B, H, W, Cin, Cout);
+    return conv_window_op(64, x, w, bias, res, nullptr, nullptr, out, B, H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
 
 int danra_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, void* stream) {

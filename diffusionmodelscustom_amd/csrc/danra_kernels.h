@@ -362,8 +362,14 @@ struct ConvWinArgs {
 // H, W powers of two (W <= 64), Cin % 64 == 0, Cout % 32 == 0 and a tile shape that fits: otherwise the caller uses launch_igemm
 bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm);
 hipError_t launch_conv_win(const ConvWinArgs& a, hipStream_t stream);
-// w [Cout][3][3][Cin] fp32 -> out (same number of bytes): scale * w split in fp16 halves, in k_conv_win's fragment order
-hipError_t launch_pack_conv_frag(const float* w, float* out, int Cout, int Cin, float scale, hipStream_t stream);
+// w [Cout][taps][Cin] fp32 -> out (same number of bytes): scale * w split in fp16 halves, in the fragment order of the
+// window kernels (k_conv_win: 9 taps; k_conv8s2: 64)
+hipError_t launch_pack_conv_frag(const float* w, float* out, int Cout, int Cin, float scale, hipStream_t stream, int taps = 9);
+// out[b][oy][ox][n] = epilogue( sum_{kh, kw, c} x[b][2 oy + kh - 3][2 ox + kw - 3][c] * w[n][kh][kw][c] ): the 8x8 stride-2
+// padding-3 convolution (kernels_conv_s2.hip), arguments as launch_conv_win's (H, W: the INPUT map; no norm on load;
+// w32 is [Cout][8][8][Cin]).  H, W powers of two >= 16, Cin % 64 == 0, Cout % 64 == 0.
+bool conv8s2_supported(int B, int H, int W, int Cin, int Cout);
+hipError_t launch_conv8s2(const ConvWinArgs& a, hipStream_t stream);
 hipError_t launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                           float* scale, float* shift, int C, hipStream_t stream);
 hipError_t launch_pack_conv(const float* w_oihw, const float* scale, float* out_ohwi, int O, int I, int KH, int KW,

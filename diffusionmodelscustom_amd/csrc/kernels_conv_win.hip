@@ -22,62 +22,14 @@
 // the whole tile: they are skipped, weights included (5 of 9 on a 2x2 map).
 #include <type_traits>
 
-#include "danra_kernels.h"
-#include "split_f16.h"
+#include "conv_window.h"
 
 namespace danra {
 
-namespace {
+using namespace convwin;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// bytes of a window pixel in LDS when CBS 64-channel blocks are staged together: per block 64 hi halves then 64 lo
-// halves, and 16 bytes at the end so that consecutive pixels rotate through the banks
-constexpr int pixel_bytes(int cbs) { return cbs * 256 + 16; }
-
-__device__ __forceinline__ void split4w(const v4f v, f16x4& hi, f16x4& lo) {
-    unsigned h[2], l[2];
-    split_pair_f16(v.x, v.y, h[0], l[0]);
-    split_pair_f16(v.z, v.w, h[1], l[1]);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    hi = __builtin_bit_cast(f16x4, (u32x2){h[0], h[1]});
-    lo = __builtin_bit_cast(f16x4, (u32x2){l[0], l[1]});
-}
-
-__device__ __forceinline__ float act_apply(int act, float v) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    return v;
-}
-
-// Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, not for its global loads.
-// (__syncthreads() also waits for every outstanding global load - vmcnt(0) - which would drain the weight ring and the
-// window loads that are meant to stay in flight across the barrier.)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-}  // namespace
-
-// Timing build of the developer harness (tune_conv_win, -DDANRA_WIN_DEBUG=1): workgroup 0 leaves clock readings of its
-// phases, per wave, in g_win_stamps.  Compiled out of the library.
-#ifndef DANRA_WIN_DEBUG
-#define DANRA_WIN_DEBUG 0
-#endif
 #if DANRA_WIN_DEBUG
 __device__ unsigned long long g_win_stamps[8 * 16];
-#define WIN_STAMP(k)                                                                        \
-    do {                                                                                    \
-        if (blockIdx.x == 0 && blockIdx.y == 0) {                                           \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
-            if (lane == 0) g_win_stamps[wave * 16 + (k)] = t_;                              \
-            __builtin_amdgcn_sched_barrier(0);                                              \
-        }                                                                                   \
-    } while (0)
-#else
-#define WIN_STAMP(k) do {} while (0)
 #endif
 
 // NPT: 32-pixel tiles per workgroup.  NW = 8 waves: wave w owns input channels 16 (w & 3) ..+15 of every 64-channel
@@ -295,6 +247,9 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
         for (int i = 0; i < NSTEPS; ++i) {
             const int j = PSPLIT ? i : grp + 2 * i;
             if ((KSTEPS % TGK) && i == NSTEPS - 1 && j >= KSTEPS) break;   // (one block of nine taps: group 1 has four steps)
+            // (keeps a step's reads, products and weight load together where the scheduler otherwise spreads the unrolled
+            // steps over one another: 1-1.5 us on the kernels with many steps per stage, nothing or a loss on the others)
+            if constexpr (CBS >= 4 || NORM) __builtin_amdgcn_sched_barrier(0);
             const int cbl = NTAPS == 4 ? j >> 2 : (j * 57) >> 9, ti = j - cbl * NTAPS;
             // where the tap's neighbour lies behind the lane's own pixel (wave-uniform)
             int toff;
@@ -424,33 +379,33 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     }
 }
 
-// w [Cout][9][Cin] fp32 (taps row-major) times `scale` (a power of two) -> fragment order of k_conv_win:
-// out[(((ct * 4 + s) * NCB + cb) * 9 + tap) * 2 + hl][lane][e], value = channel 32 ct + (lane & 31), tap, input channel
+// w [Cout][taps][Cin] fp32 (taps row-major) times `scale` (a power of two) -> fragment order of the window kernels:
+// out[(((ct * 4 + s) * NCB + cb) * taps + tap) * 2 + hl][lane][e], value = channel 32 ct + (lane & 31), tap, input channel
 // 64 cb + 16 s + 8 (lane >> 5) + e; hi = rounded towards zero to fp16, lo = the remainder (as k_split_weights forms them).
 __global__ __launch_bounds__(256) void k_pack_conv_frag(const float* __restrict__ w, _Float16* __restrict__ out, int Cout,
-                                                        int Cin, float scale) {
+                                                        int Cin, float scale, int taps) {
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
     const int NCB = Cin >> 6;
-    const size_t total = (size_t)Cout * 9 * Cin;
+    const size_t total = (size_t)Cout * taps * Cin;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int nrow = (int)(i / ((size_t)9 * Cin));
-        const int rem = (int)(i - (size_t)nrow * 9 * Cin);
+        const int nrow = (int)(i / ((size_t)taps * Cin));
+        const int rem = (int)(i - (size_t)nrow * taps * Cin);
         const int tap = rem / Cin, c = rem - tap * Cin;
         const float v = w[i] * scale;
         const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
         const int ct = nrow >> 5, cb = c >> 6, s = (c >> 4) & 3, hh = (c >> 3) & 1, e = c & 7;
         const int ln = (nrow & 31) + 32 * hh;
-        const size_t frag = ((size_t)((ct * 4 + s) * NCB + cb) * 9 + tap) * 2;
+        const size_t frag = ((size_t)((ct * 4 + s) * NCB + cb) * taps + tap) * 2;
         out[(frag * 64 + ln) * 8 + e] = (_Float16)h[0];
         out[((frag + 1) * 64 + ln) * 8 + e] = (_Float16)(v - (float)h[0]);
     }
 }
 
-hipError_t launch_pack_conv_frag(const float* w, float* out, int Cout, int Cin, float scale, hipStream_t stream) {
-    if (Cout % 32 || Cin % 64) return hipErrorInvalidValue;
-    int blocks = (int)(((size_t)Cout * 9 * Cin + 255) / 256);
+hipError_t launch_pack_conv_frag(const float* w, float* out, int Cout, int Cin, float scale, hipStream_t stream, int taps) {
+    if (Cout % 32 || Cin % 64 || taps <= 0) return hipErrorInvalidValue;
+    int blocks = (int)(((size_t)Cout * taps * Cin + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_pack_conv_frag, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), Cout, Cin, scale);
+    hipLaunchKernelGGL(k_pack_conv_frag, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<_Float16*>(out), Cout, Cin, scale, taps);
     return hipGetLastError();
 }
 

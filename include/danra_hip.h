@@ -355,6 +355,12 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap_nhwc, con
  * Cout % 32 == 0.  Allocates a temporary copy of the weights and waits for the stream. */
 int danra_conv3x3(const float* x_nhwc, const float* w, const float* bias, const float* res_nhwc, const float* nmean,
                   const float* nrstd, float* out_nhwc, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* One 8x8 stride-2 padding-3 convolution as Encoder.conv2 applies it (modules:186-191, 269-273; bn1 folded into w and
+ * bias by the caller), through the strided window kernel, for unit tests: NHWC x [B][H][W][Cin] -> [B][H/2][W/2][Cout],
+ * w [Cout][8][8][Cin], optional bias, residual (NHWC, added before the optional ReLU).  H, W powers of two >= 16,
+ * Cin % 64 == 0, Cout % 64 == 0.  Allocates a temporary copy of the weights and waits for the stream. */
+int danra_conv8x8s2(const float* x_nhwc, const float* w, const float* bias, const float* res_nhwc, float* out_nhwc, int B,
+                    int H, int W, int Cin, int Cout, int relu, void* stream);
 /* InstanceNorm2d(affine=False, eps=1e-5) (modules:412,419) on NHWC. */
 int danra_instance_norm(const float* x_nhwc, float* out_nhwc, int B, int HW, int C, void* stream);
 /* danra_instance_norm for callers that cannot allocate device memory (code under hipGraph capture, serving loops,

@@ -123,3 +123,16 @@ def conv3x3(lib, x, w, bias=None, res=None, norm=None, relu=False):
     _check(lib, lib.danra_conv3x3(_ptr(xin), _ptr(wp), _ptr(bias), _ptr(rin), _ptr(mean), _ptr(rstd), _ptr(out), B, H, W, Cin,
                                   Cout, int(relu), _stream()), "danra_conv3x3")
     return to_nchw(lib, out)
+
+
+def conv8x8s2(lib, x, w, bias=None, res=None, relu=False):
+    """danra_conv8x8s2 on NCHW tensors: x [B, Cin, H, W], w [Cout, Cin, 8, 8] (torch layout) -> [B, Cout, H/2, W/2]."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xin = to_nhwc(lib, x)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    rin = None if res is None else to_nhwc(lib, res)
+    out = torch.empty((B, H // 2, W // 2, Cout), device=x.device, dtype=torch.float32)
+    _check(lib, lib.danra_conv8x8s2(_ptr(xin), _ptr(wp), _ptr(bias), _ptr(rin), _ptr(out), B, H, W, Cin, Cout, int(relu),
+                                    _stream()), "danra_conv8x8s2")
+    return to_nchw(lib, out)

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --timesteps 12 --no-cpu-baseline --no-kernel-timing > "$OUT/fetch.log" 2>&1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --timesteps 12 --no-cpu-baseline --no-kernel-timing > "$OUT/write.log" 2>&1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --timesteps 12 --no-cpu-baseline --no-kernel-timing --no-strict-fp32 > "$OUT/fetch.log" 2>&1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --timesteps 12 --no-cpu-baseline --no-kernel-timing --no-strict-fp32 > "$OUT/write.log" 2>&1
 ls -la "$OUT"/fetch "$OUT"/write
 head -3 "$OUT"/fetch/*counter_collection.csv
