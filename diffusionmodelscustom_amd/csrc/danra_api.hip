@@ -99,7 +99,7 @@ struct Workspace {
     int B = 0, H = 0, W = 0;
     void* base = nullptr;
     size_t bytes = 0;
-    float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *obuf, *up, *cv, *pre, *outA, *outB;
+    float *tbias, *f1pre, *c2, *rt[4], *fpre[5], *fmap[5], *qkv, *kv_split, *kv_flags, *obuf, *up, *cv, *pre, *outA, *outB;
     float *mean1, *rstd1, *mean2, *rstd2, *partial, *eps, *eps_uncond, *stats_part, *zeros, *stem_static;
     size_t stats_part_floats = 0;
     size_t partial_floats = 0;
@@ -139,6 +139,8 @@ struct danra_handle_s {
     // DANRA_FUSED_SMALL_ATTENTION=0 keeps the three-kernel form of the short-sequence attention blocks (comparison runs)
     bool fused_small_attention = !(getenv("DANRA_FUSED_SMALL_ATTENTION") && atoi(getenv("DANRA_FUSED_SMALL_ATTENTION")) == 0);
     // DANRA_CONV_WIN=0: every convolution through the implicit-GEMM kernel (comparison runs)
+    // DANRA_PRESPLIT=0: the QKV projections leave fp32 K and V and the attention core splits them tile by tile (comparison runs)
+    bool presplit = !(getenv("DANRA_PRESPLIT") && atoi(getenv("DANRA_PRESPLIT")) == 0);
     bool conv_win = !(getenv("DANRA_CONV_WIN") && atoi(getenv("DANRA_CONV_WIN")) == 0);
     bool conv_s2 = !(getenv("DANRA_CONV_S2") && atoi(getenv("DANRA_CONV_S2")) == 0);   // ... only the 8x8 stride-2 one
     SplitW final_s_wt;
@@ -547,6 +549,8 @@ int ensure_workspace(danra_handle_s* h, int B, int H, int W) {
             hw /= 4;
         }
         ws.qkv = bp.take(3 * B * hw2 * 64);
+        ws.kv_split = bp.take(2 * B * hw2 * 64);   // K and V of the 64-channel blocks as their attention core reads them
+        ws.kv_flags = bp.take(B * hw2 / 2 + 64);   // ... and their range flags (ints): two per group of 16 keys and head
         ws.obuf = bp.take(B * hw2 * 64);
         ws.up = bp.take((size_t)B * H * W * 64);
         ws.cv = bp.take(B * hw2 * 64);
@@ -810,16 +814,28 @@ int run_attention(danra_handle_s* h, int index, const float* x, float* out, int 
         a.st_mode = ST_QKV; a.qkv_C = C; a.qkv_hd = hd; a.qkv_L = L; a.qkv_heads = heads;
         a.qkv_plane = (long long)B * L * C;
         choose_split(a, ws);
-        if (lean_qkv)  // few tokens: one trip to memory per wave instead of a tiled GEMM
-            HIP_TRY(launch_qkv_small(x, at.w_in_frag, at.w_in, at.s_in.inv_scale, at.b_in, ws.qkv, B * L, C, L, hd, st));
-        else
-            RC_TRY(igemm(h, a, st));
         const size_t plane = (size_t)B * L * C;
+        // head_dim 16 at L % 128 == 0 (the flash core): K and V leave the projection kernel already split, in the order of
+        // the core's LDS tiles, with their range flags; the fp32 K / V planes are written only for flagged groups of keys
+        const bool pre = h->presplit && hd == 16 && L % 128 == 0 && !igemm_fp32_products_forced() &&
+                         (lean_qkv ? qkv_small_presplits(B * L, C, L, hd) : gemm_k64_presplits(a));
+        float* ks = pre ? ws.kv_split : nullptr;
+        float* vs = pre ? ws.kv_split + plane : nullptr;
+        int* kvf = pre ? reinterpret_cast<int*>(ws.kv_flags) : nullptr;
+        if (lean_qkv)  // few tokens: one trip to memory per wave instead of a tiled GEMM
+            HIP_TRY(launch_qkv_small(x, at.w_in_frag, at.w_in, at.s_in.inv_scale, at.b_in, ws.qkv, B * L, C, L, hd, st, ks, vs, kvf));
+        else {
+            a.pre_ks = ks; a.pre_vs = vs; a.pre_flags = kvf;
+            RC_TRY(igemm(h, a, st));
+        }
         const bool flash = (hd == 16 && L % 128 == 0) || ((hd == 32 || hd == 64) && L % 64 == 0 && L >= 256);
         const bool timed = (h->prof_kind == DANRA_PROF_FLASH_ATTENTION && h->prof_now && flash);
         {
             ProfScope scope(h, timed);
-            HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
+            if (pre)
+                HIP_TRY(launch_attention_hd16_pre(ws.qkv, ks, vs, ws.qkv + plane, ws.qkv + 2 * plane, kvf, ws.obuf, B, heads, L, st));
+            else
+                HIP_TRY(launch_attention(ws.qkv, ws.qkv + plane, ws.qkv + 2 * plane, ws.obuf, B, heads, L, hd, st));
         }
         if (timed) {
             const double fl = 4.0 * (double)B * heads * (double)L * (double)L * hd;  // QK^T and PV, 2 flop per MAC
@@ -1312,6 +1328,24 @@ int danra_attention_core_fwd(const float* q, const float* k, const float* v, flo
     if (!q || !k || !v || !out) return fail(DANRA_EINVAL, "null argument");
     if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
     HIP_TRY(launch_attention_hd16(q, k, v, out, lse2, B, heads, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_attention_core_presplit_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L,
+                                      int head_dim, void* stream) {
+    if (!q || !k || !v || !out) return fail(DANRA_EINVAL, "null argument");
+    if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = (size_t)B * heads * L * 16;
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, (2 * plane + (size_t)B * heads * (L / 16) * 2) * sizeof(float)) != hipSuccess)
+        return fail(DANRA_ENOMEM, "temporary buffer for the split K and V");
+    int* flags = reinterpret_cast<int*>(tmp + 2 * plane);
+    hipError_t e = launch_presplit_kv(k, v, tmp, tmp + plane, flags, B * heads, L, st);
+    if (e == hipSuccess) e = launch_attention_hd16_pre(q, tmp, tmp + plane, k, v, flags, out, B, heads, L, st);
+    const hipError_t se = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess || se != hipSuccess) return fail(DANRA_EHIP, "pre-split attention core: %s", hipGetErrorString(e != hipSuccess ? e : se));
     return DANRA_OK;
 }
 

@@ -72,12 +72,20 @@ struct IGemmArgs {
     int force_bm, force_kw;        // 0 = let the launcher choose the tile (tuning / tests)
     int keep_slabs;                // split-K only: leave the slabs in `partial` (no reduction kernel); the consumer sums them
     int half;                      // != 0: multiply on the fp16 matrix cores with operands split in two fp16 halves (k_igemm HALF)
+    // ST_QKV with head_dim 16 through the K = 64 kernel (gemm_k64_presplits): K and V leave the kernel in the pre-split form
+    // of the attention core (launch_presplit_kv describes it), with their range flags; the fp32 K / V planes of `out` are
+    // then written only for the groups of keys whose flag is set.  All three or none.
+    float* pre_ks;
+    float* pre_vs;
+    int* pre_flags;
     // filled in by launch_igemm: log2 of a divisor of the row decomposition when it is a power of two, else -1
     // (rows_per_img, batch, Ho*Wo, Wo, qkv_L, ct_H*ct_W, ct_W): the kernels then shift instead of dividing
     int sh_rpi, sh_batch, sh_howo, sh_wo, sh_qkv_l, sh_ct_hw, sh_ct_w;
     int debug;                     // timing ablations of tune_igemm (results are wrong): 1 = always stage chunk 0, 2 = no MFMA, 4 = no LDS store/barrier
 };
 hipError_t launch_igemm(const IGemmArgs& a, hipStream_t stream);
+// whether launch_igemm would run `a` (a QKV projection) through the kernel that can leave K and V pre-split
+bool gemm_k64_presplits(const IGemmArgs& a);
 // on != 0: every later launch_igemm multiplies with fp32 matrix instructions whatever `half` says.  Process-wide; for
 // numerical cross-checks.
 void set_igemm_fp32_products(int on);
@@ -111,6 +119,12 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
 
 // ---------------------------------------------------------------- attention
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
+// K, V [n_bh][L][16] -> the pre-split form of the head_dim-16 core (ks, vs: as many bytes as k, v; flags: 2 * n_bh * L / 16
+// ints), and that core on it; k32 / v32 are read only where a flag is set (kernels_attn.hip, k_flash_hd16 PRE).
+hipError_t launch_presplit_kv(const float* k, const float* v, float* ks, float* vs, int* flags, int n_bh, int L,
+                              hipStream_t stream);
+hipError_t launch_attention_hd16_pre(const float* q, const float* ks, const float* vs, const float* k32, const float* v32,
+                                     const int* flags, float* out, int B, int heads, int L, hipStream_t stream);
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* out, int B, int heads,
                             int L, int hd, hipStream_t stream);
 // LayerNorm + QKV projection of one head + that head's attention as one kernel per (image, head), for the short
@@ -134,8 +148,12 @@ bool proj_small_supported(int M, int N, int K);
 // through the same kernel: x [M][C], w_frag / w / bias = in_proj [3C][C] with the LayerNorm affine folded in,
 // qkv [3][M / L * heads][L][hd].
 bool qkv_small_supported(int M, int C, int L, int hd);
+// pre_ks / pre_vs / pre_flags (all or none; qkv_small_presplits): K and V leave the kernel in the pre-split form of the
+// head_dim-16 attention core (launch_presplit_kv), the fp32 K / V planes of `qkv` are written only where a flag is set.
+bool qkv_small_presplits(int M, int C, int L, int hd);
 hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
-                            int M, int C, int L, int hd, hipStream_t stream);
+                            int M, int C, int L, int hd, hipStream_t stream, float* pre_ks = nullptr, float* pre_vs = nullptr,
+                            int* pre_flags = nullptr);
 // w [rows][K] fp32 -> scale * w split in fp16 halves in the fragment order of launch_split_to_frag16 (rows % 16 == 0, K % 32 == 0)
 hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, float scale, hipStream_t stream);
 // With ct_W != 0: a kernel-2 stride-2 transposed convolution on a ct_H x ct_W map (N = 4 x channels), rows stored

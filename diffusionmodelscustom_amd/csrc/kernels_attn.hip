@@ -68,11 +68,25 @@ static constexpr int KHROW = 32;  // halves per key row of the fp16 K tile
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // KT64: 64-key sub-tiles per staged tile (one barrier per 64 * KT64 keys; 2 measured equal to 1 within the run-to-run
 // spread, in tune_flash and in the network, so the library uses 1)
-template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH, int KT64 = 1>
+//
+// PRE: K and V arrive already split, in the order of the LDS tiles, from the kernels that produce them (the QKV
+// projections of the network, or launch_presplit_kv): K and V then point at those copies, staging a tile is a straight
+// 8 KB copy with no arithmetic, and the range test has been made by the producer: pre.flags holds, per (image, head) and
+// group of 16 keys, whether K (word 0) or V (word 1) of that group left the range of the split.  Only for such a group
+// does the producer also write the fp32 values (pre.k32 / pre.v32, the [key][16] layout of the other form): a tile with
+// a flagged group, and every tile of a wave whose own queries leave the fp16 range, is multiplied with the fp32
+// instructions, per group from the fp32 values where they exist and from the sum of the halves (22 bits) elsewhere.
+struct FlashPre {
+    const float* k32;
+    const float* v32;
+    const int* flags;
+};
+template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH, int KT64 = 1, bool PRE = false>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
-                                                    float scale_log2e) {
+                                                    float scale_log2e, const FlashPre pre) {
+    static_assert(!PRE || (PVH && QKH && KT64 == 1), "pre-split operands: the fp16 form, 64 keys per tile");
     // fp32 tiles only in the all-fp32 form; the fp32 fallback of the fp16 forms (rare) reads global memory instead
     constexpr bool F32_TILES = !(PVH && QKH);
     __shared__ __attribute__((aligned(16))) float Ks[F32_TILES ? 2 : 1][F32_TILES ? KT64 * KVT * KROW : 4];
@@ -86,6 +100,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     // kt + 2 while a slower wave still decides about tile kt + 1, and which products that wave then used would depend on
     // timing; a buffer's flag is only written again behind the barrier that ends the iteration that read it.
     __shared__ int vbig_s[2];
+    __shared__ int grp_s[PRE ? 2 : 1][8];   // PRE: the producer's flags of the staged tile: [16-key group][K, V]
     static_assert(PVH == QKH, "both products run on the fp16 matrix cores, or neither");
     constexpr float RESCALE = PVH ? 15.f : RESCALE_LOG2;  // log2 of the largest probability relative to the reference
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,7 +192,14 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int vkey = 32 * vhalf + 16 * vj + 4 * vg;  // first of this thread's four keys within a tile
     constexpr int TK = KT64 * KVT;  // keys per staged tile
     float4 kreg[KT64], vreg[KT64];
+    int flag_reg = 0;
     auto load_kv = [&](int tile) {
+        if constexpr (PRE) {  // 4 KB of K rows and 4 KB of V fragments, both in the order of their LDS tiles
+            kreg[0] = *reinterpret_cast<const float4*>(Kb + (size_t)tile * 1024 + tid * 4);
+            vreg[0] = *reinterpret_cast<const float4*>(Vb + (size_t)tile * 1024 + tid * 4);
+            if (tid < 8) flag_reg = pre.flags[((size_t)bh * (L / 16) + 4 * tile) * 2 + tid];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < KT64; ++u) {
             kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(tile * TK + KVT * u + srow) * 16 + sc4);
@@ -201,6 +223,16 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto stage = [&](int buf) {
+        if constexpr (PRE) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(&Kh[buf][0]) + tid * 4) = kreg[0];
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(&Vh[buf][0][0][0]) + tid * 4) = vreg[0];
+            if (wave == 0) {
+                const bool any = __any(tid < 8 && flag_reg != 0) != 0;
+                if (tid < 8) grp_s[buf][tid] = flag_reg;
+                if (tid == 0) vbig_s[buf] = any ? 1 : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < KT64; ++u) {
             const float4 kr = kreg[u], vr = vreg[u];
@@ -240,10 +272,12 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int ntiles = L / TK;
     // fp32 products: always in the all-fp32 form; in the fp16 form from the first tile on for a wave whose own queries
     // leave the fp16 range, and for every wave from the first flagged K / V tile on
-    bool vbig = PVH ? (__any(!q_bounded) != 0) : true;
+    const bool q_big = PVH ? (__any(!q_bounded) != 0) : true;
+    bool vbig = q_big;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = (ABL & 4) ? 0 : (kt & 1);
-        vbig = vbig || (__builtin_amdgcn_readfirstlane(vbig_s[buf]) != 0);  // from the first flagged tile on
+        if constexpr (PRE) vbig = q_big || (__builtin_amdgcn_readfirstlane(vbig_s[buf]) != 0);   // this tile only
+        else vbig = vbig || (__builtin_amdgcn_readfirstlane(vbig_s[buf]) != 0);  // from the first flagged tile on
         {   // unconditional prefetch (the last tile re-reads itself): a load under a condition is waited for on the spot
             const int nxt = min(kt + 1, ntiles - 1);
             load_kv(nxt);
@@ -269,9 +303,20 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                     }
                     continue;
                 }
-                const float4 kf = F32_TILES
-                    ? *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g])
-                    : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * TK + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
+                float4 kf;
+                if constexpr (PRE) {
+                    if (grp_s[buf][(2 * hf + j) * 2] != 0) {   // the producer left this group's fp32 values
+                        kf = *reinterpret_cast<const float4*>(pre.k32 + ((size_t)bh * L + kt * TK + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
+                    } else {                                    // the sum of the halves
+                        const f16x8 kk = *reinterpret_cast<const f16x8*>(&Kh[buf][((2 * hf + j) * 16 + lq) * KHROW + 8 * g]);
+                        kf = make_float4((float)kk[0] + (float)kk[4] * 0.00048828125f, (float)kk[1] + (float)kk[5] * 0.00048828125f,
+                                         (float)kk[2] + (float)kk[6] * 0.00048828125f, (float)kk[3] + (float)kk[7] * 0.00048828125f);
+                    }
+                } else {
+                    kf = F32_TILES
+                        ? *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g])
+                        : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * TK + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
+                }
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     f32x4 a = negm[t];
@@ -365,11 +410,24 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {  // fp32: lane (d, g) holds V[key 4g + r][d] for step r
                 float vf[4];
+                if constexpr (PRE) {
+                    if (grp_s[buf][(2 * hf + j) * 2 + 1] != 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            vf[r] = pre.v32[((size_t)bh * L + kt * TK + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
+                    } else {
+                        const f16x4 vh4 = *reinterpret_cast<const f16x4*>(&Vh[buf][0][hf][(lq * 4 + g) * 8 + 4 * j]);
+                        const f16x4 vl4 = *reinterpret_cast<const f16x4*>(&Vh[buf][1][hf][(lq * 4 + g) * 8 + 4 * j]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vf[r] = (float)vh4[r] + (float)vl4[r] * 0.00048828125f;
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     vf[r] = (ABL & 2) ? scale_log2e + (float)r
                           : F32_TILES ? Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq]
                                       : Vb[(size_t)(kt * TK + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
+                }
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -1174,7 +1232,8 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
                                                     const float* __restrict__ W, float wscale,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                     float* __restrict__ out, int M, int N, int act, int qkv_L,
-                                                    int qkv_hd, int ct_H, int ct_W) {
+                                                    int qkv_hd, int ct_H, int ct_W, float* __restrict__ pre_ks,
+                                                    float* __restrict__ pre_vs, int* __restrict__ pre_flags) {
     constexpr int K = 32 * KS;
     const int lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
     const int task = blockIdx.x;  // one wave per workgroup: a few hundred tasks spread over all CUs
@@ -1241,6 +1300,7 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
 #pragma unroll
     for (int t = 0; t < NCT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float scale = wscale;
+    const bool pre_v = QKV && pre_flags != nullptr && cg == 2;   // this wave forms V for the pre-split form: untransposed
     if (__any(bad)) {  // rare: fp32 instructions, the fp32 matrix straight from memory (k = 32 s + 8 kg + e on both sides)
         scale = 1.0f;
         for (int t = 0; t < NCT; ++t) {
@@ -1269,10 +1329,66 @@ __global__ __launch_bounds__(64) void k_proj_small(const float* __restrict__ A, 
             const f16x8 xl = __builtin_bit_cast(f16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
+                if (QKV && pre_v) {   // rows as the A operand: the same products, term by term, untransposed
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[t][s2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[t][s2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[t][s2], acc[t], 0, 0, 0);
+                    continue;
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][s2], xh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][s2], xl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][s2], xh, acc[t], 0, 0, 0);
             }
+        }
+    }
+    if constexpr (QKV) {
+        // ---- K and V of a head_dim-16 block left pre-split for the attention core (launch_presplit_kv describes the
+        // form): this wave holds 16 keys of one image; its column tiles are the heads
+        if (pre_flags != nullptr && cg >= 1) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int row0 = rt * 16, b = row0 / qkv_L, l0 = row0 - b * qkv_L, heads = NCT;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int bh = b * heads + t;
+                int* fl = pre_flags + ((size_t)bh * (qkv_L >> 4) + (l0 >> 4)) * 2;
+                if (cg == 1) {   // K: lane (key c, kg) holds columns 4 kg .. + 3
+                    const float4 v = make_float4(acc[t][0] * scale + bv[t].x, acc[t][1] * scale + bv[t].y, acc[t][2] * scale + bv[t].z,
+                                                 acc[t][3] * scale + bv[t].w);
+                    unsigned h2[2], l2[2];
+                    split_scaled_pair_f16(v.x, v.y, h2[0], l2[0]);
+                    split_scaled_pair_f16(v.z, v.w, h2[1], l2[1]);
+                    *reinterpret_cast<u32x4*>(pre_ks + ((size_t)bh * qkv_L + l0 + c) * 16 + 4 * kg) = u32x4{h2[0], h2[1], l2[0], l2[1]};
+                    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    const bool flagged = __any(!(m < 32768.f)) != 0;
+                    if (lane == 0) fl[0] = flagged ? 1 : 0;
+                    if (flagged)   // (rare) the group's fp32 values
+                        *reinterpret_cast<float4*>(out + (size_t)M * (N / 3) + ((size_t)bh * qkv_L + l0 + c) * 16 + 4 * kg) = v;
+                } else {         // V, formed untransposed: lane (column c, kg) holds keys 4 kg .. + 3
+                    const float bc = bias ? bias[(cg * NCT + t) * 16 + c] : 0.f;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * scale + bc;
+                    unsigned h2[2], l2[2];
+                    split_scaled_pair_f16(v[0], v[1], h2[0], l2[0]);
+                    split_scaled_pair_f16(v[2], v[3], h2[1], l2[1]);
+                    // slot 4 j + r of group g = kg, column d = c, in the 32-key half this group of 16 belongs to
+                    float* vt = pre_vs + ((size_t)bh * qkv_L + (l0 & ~63)) * 16;
+                    const int half = (l0 >> 5) & 1, j = (l0 >> 4) & 1;
+                    const int at = (half * 512 + (c * 4 + kg) * 8 + 4 * j) / 2;
+                    *reinterpret_cast<u32x2*>(vt + at) = u32x2{h2[0], h2[1]};
+                    *reinterpret_cast<u32x2*>(vt + 512 + at) = u32x2{l2[0], l2[1]};
+                    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    const bool flagged = (__any(!(m < 32768.f)) != 0) || (__all(m < 0.0009765625f) != 0);
+                    if (lane == 0) fl[1] = flagged ? 1 : 0;
+                    if (flagged) {
+                        float* v32 = out + 2 * (size_t)M * (N / 3) + ((size_t)bh * qkv_L + l0 + 4 * kg) * 16 + c;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v32[r * 16] = v[r];
+                    }
+                }
+            }
+            return;
         }
     }
     if (rt * 16 + c >= M) return;
@@ -1308,6 +1424,8 @@ bool proj_small_supported(int M, int N, int K) {
     return per_wave && N >= per_wave && N % per_wave == 0 && M >= 1 && M <= (K == 64 ? 65536 : 8192);
 }
 
+static float* const no_f = nullptr;
+static int* const no_i = nullptr;
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
                              const float* res, float* out, int M, int N, int K, int act, hipStream_t stream, int ct_H,
                              int ct_W, bool layernorm) {
@@ -1318,24 +1436,24 @@ hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w
         const _Float16* wfl = reinterpret_cast<const _Float16*>(w_frag);
         const int rtl = (M + 15) / 16;
         if (K == 128)
-            DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true>), dim3(rtl * (N / 128)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+            DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true>), dim3(rtl * (N / 128)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0, no_f, no_f, no_i);
         else if (K == 256)
-            DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true>), dim3(rtl * (N / 64)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+            DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true>), dim3(rtl * (N / 64)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0, no_f, no_f, no_i);
         else
-            DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true>), dim3(rtl * (N / 32)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0);
+            DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true>), dim3(rtl * (N / 32)), dim3(64), 0, stream, a, wfl, w, wscale, bias, res, out, M, N, act, 0, 0, 0, 0, no_f, no_f, no_i);
         return hipGetLastError();
     }
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
     // NCT * KS = 32 fragment pairs per wave: 128 columns per wave at K = 128, 64 at 256, 32 at 512 (64 at K = 64)
     if (K == 64)
-        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W, no_f, no_f, no_i);
     else if (K == 128)
-        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8>), dim3(rts * (N / 128)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W, no_f, no_f, no_i);
     else if (K == 256)
-        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4>), dim3(rts * (N / 64)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W, no_f, no_f, no_i);
     else
-        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W);
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2>), dim3(rts * (N / 32)), dim3(64), 0, stream, a, wf, w, wscale, bias, res, out, M, N, act, 0, 0, ct_H, ct_W, no_f, no_f, no_i);
     return hipGetLastError();
 }
 
@@ -1349,20 +1467,93 @@ bool qkv_small_supported(int M, int C, int L, int hd) {
     return (C == 64 || C == 128 || C == 256 || C == 512) && M >= 1 && M <= max_rows && hd % 4 == 0 && C % hd == 0 && L >= 1 &&
            M % L == 0;
 }
+bool qkv_small_presplits(int M, int C, int L, int hd) { return qkv_small_supported(M, C, L, hd) && C == 64 && hd == 16 && L % 64 == 0; }
 hipError_t launch_qkv_small(const float* x, const float* w_frag, const float* w, float wscale, const float* bias, float* qkv,
-                            int M, int C, int L, int hd, hipStream_t stream) {
+                            int M, int C, int L, int hd, hipStream_t stream, float* pre_ks, float* pre_vs, int* pre_flags) {
     if (!qkv_small_supported(M, C, L, hd) || !w_frag || !w) return hipErrorInvalidValue;
+    if ((pre_ks || pre_vs || pre_flags) && !(pre_ks && pre_vs && pre_flags && qkv_small_presplits(M, C, L, hd))) return hipErrorInvalidValue;
     const _Float16* wf = reinterpret_cast<const _Float16*>(w_frag);
     const int rts = (M + 15) / 16;
     const float* none = nullptr;
     if (C == 64)  // three waves per 16 tokens (q, k, v; each normalises the rows again): 64 registers instead of 172, 9.2 against 9.6 us
-        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<2, 4, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0, pre_ks, pre_vs, pre_flags);
     else if (C == 128)
-        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<4, 8, true, true>), dim3(rts * 3), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0, no_f, no_f, no_i);
     else if (C == 256)
-        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true, true>), dim3(rts * 12), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<8, 4, true, true>), dim3(rts * 12), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0, no_f, no_f, no_i);
     else
-        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true, true>), dim3(rts * 48), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0);
+        DANRA_LAUNCH_KERNEL((k_proj_small<16, 2, true, true>), dim3(rts * 48), dim3(64), 0, stream, x, wf, w, wscale, bias, none, qkv, M, 3 * C, 0, L, hd, 0, 0, no_f, no_f, no_i);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K and V of the head_dim-16 core [B*heads][L][16] in the pre-split form k_flash_hd16<PRE> reads (what the network's QKV
+// projections write directly): one workgroup per (image, head, 64-key tile).
+//   ks: per key 64 bytes, four groups of [4 halves hi | 4 halves lo'] (columns 4g .. 4g + 3), x = hi + 2^-11 lo'
+//   vs: per tile [hi, lo'][32-key half][d][g][8 halves], slot 4j + r <-> key 16 j + 4 g + r of the half
+//   flags: per 16 keys [K, V]: 1 where the group leaves the range of the split (a value of 2^15 or more or non-finite; for
+//          V also nothing of 2^-10 or more)
+
+__global__ __launch_bounds__(256) void k_presplit_kv(const float* __restrict__ K, const float* __restrict__ V,
+                                                     float* __restrict__ ks, float* __restrict__ vs, int* __restrict__ flags,
+                                                     int L) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tiles = L / 64;
+    const int bh = blockIdx.x / tiles, tile = blockIdx.x - bh * tiles;
+    {   // K: thread = (key, column group); a wave = one group of 16 keys
+        const int key = tile * 64 + (tid >> 2), g = tid & 3;
+        const float4 k = *reinterpret_cast<const float4*>(K + ((size_t)bh * L + key) * 16 + 4 * g);
+        unsigned h[2], l[2];
+        split_scaled_pair_f16(k.x, k.y, h[0], l[0]);
+        split_scaled_pair_f16(k.z, k.w, h[1], l[1]);
+        *reinterpret_cast<u32x4*>(ks + ((size_t)bh * L + key) * 16 + 4 * g) = u32x4{h[0], h[1], l[0], l[1]};
+        const float kmax = fmaxf(fmaxf(fabsf(k.x), fabsf(k.y)), fmaxf(fabsf(k.z), fabsf(k.w)));
+        const bool bad = __any(!(kmax < 32768.f)) != 0;
+        if ((tid & 63) == 0) flags[((size_t)bh * (L / 16) + 4 * tile + wave) * 2] = bad ? 1 : 0;
+    }
+    if (tid < 128) {   // V: thread = (32-key half, d, g); a wave = one half = two groups of 16 keys
+        const int half = tid >> 6, d = (tid >> 2) & 15, g = tid & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[4 * j + r] = V[((size_t)bh * L + tile * 64 + half * 32 + 16 * j + 4 * g + r) * 16 + d];
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_scaled_pair_f16(v[2 * e], v[2 * e + 1], h[e], l[e]);
+        float* base = vs + ((size_t)bh * L + tile * 64) * 16;             // this tile's 4 KB
+        const int at = (half * 512 + (d * 4 + g) * 8) / 2;                // floats; hi block, then lo (2 x 512 halves further)
+        *reinterpret_cast<u32x4*>(base + at) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(base + 512 + at) = u32x4{l[0], l[1], l[2], l[3]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float m = fmaxf(fmaxf(fabsf(v[4 * j]), fabsf(v[4 * j + 1])), fmaxf(fabsf(v[4 * j + 2]), fabsf(v[4 * j + 3])));
+            const bool bad = (__any(!(m < 32768.f)) != 0) || (__all(m < 0.0009765625f) != 0);
+            if ((tid & 63) == 0) flags[((size_t)bh * (L / 16) + 4 * tile + 2 * half + j) * 2 + 1] = bad ? 1 : 0;
+        }
+    }
+}
+
+hipError_t launch_presplit_kv(const float* k, const float* v, float* ks, float* vs, int* flags, int n_bh, int L,
+                              hipStream_t stream) {
+    if (L % 64 || n_bh <= 0) return hipErrorInvalidValue;
+    DANRA_LAUNCH_KERNEL(k_presplit_kv, dim3(n_bh * (L / 64)), dim3(256), 0, stream, k, v, ks, vs, flags, L);
+    return hipGetLastError();
+}
+
+// The head_dim-16 core on pre-split K and V (see k_flash_hd16 PRE).  k32 / v32: the fp32 values, read only for the groups
+// of 16 keys whose flag is set.
+hipError_t launch_attention_hd16_pre(const float* q, const float* ks, const float* vs, const float* k32, const float* v32,
+                                     const int* flags, float* out, int B, int heads, int L, hipStream_t stream) {
+    if (L % 128 != 0 || !flags) return hipErrorInvalidValue;
+    const float scale_log2e = 0.25f * 1.4426950408889634f;
+    dim3 grid((L / 128) * B * heads);
+    const FlashPre pre{k32, v32, flags};
+    float* no_lse = nullptr;
+    DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, true, true, 1, true>), grid, dim3(256), 0, stream, q, ks, vs, out, no_lse, L, heads,
+                       B * heads, scale_log2e, pre);
     return hipGetLastError();
 }
 
@@ -1374,11 +1565,12 @@ hipError_t launch_attention_hd16(const float* q, const float* k, const float* v,
     if (L % 128 != 0) return hipErrorInvalidValue;
     const float scale_log2e = 0.25f * 1.4426950408889634f;
     dim3 grid((L / 128) * B * heads);
+    const FlashPre no_pre{nullptr, nullptr, nullptr};
     if (g_hd16_fp32_products)
         DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, false, false>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads,
-                           B * heads, scale_log2e);
+                           B * heads, scale_log2e, no_pre);
     else
-        DANRA_LAUNCH_KERNEL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e);
+        DANRA_LAUNCH_KERNEL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e, no_pre);
     return hipGetLastError();
 }
 

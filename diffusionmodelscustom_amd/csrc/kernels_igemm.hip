@@ -883,6 +883,37 @@ __device__ __forceinline__ f32x16 tile64_half(const float* Bs, const f16x8 (&ah)
     }
     return acc;
 }
+// The same products untransposed (activations as the A operand): lane (column, h) ends up with rows 8 u + 4 h + e of its
+// column in acc[4 u + e] - four consecutive rows of one column per register group, the order in which the attention
+// core's V fragments hold their keys.  Identical arithmetic, term by term.
+__device__ __forceinline__ f32x16 tile64_half_rows(const float* Bs, const f16x8 (&ah)[4], const f16x8 (&al)[4]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(Bs + st * 8);
+        const f16x8 wl = *reinterpret_cast<const f16x8*>(Bs + st * 8 + 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st], wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], wh, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 tile64_f32_rows(const float* Bs, const float4 (&a)[8]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const float4 b = *reinterpret_cast<const float4*>(Bs + kb * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb].x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb].y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb].z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb].w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
 __device__ __forceinline__ f32x16 tile64_f32(const float* Bs, const float4 (&a)[8]) {
     f32x16 acc;
 #pragma unroll
@@ -997,7 +1028,67 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
     const float out_scale = (HALF && split_ok) ? p.wscale : 1.0f;  // the split weights carry a power-of-two scale
     const int ldw = p.ldw ? p.ldw : 64;
 
+    // ---- QKV projection of a head_dim-16 block with K and V left pre-split for the attention core (p.pre_*): a tile
+    // of 32 columns is two heads of q, k or v; the wave's 32 rows are two groups of 16 keys of one image
+    const bool presplit = HALF && p.pre_flags != nullptr;
+    const int pre_b = presplit ? div_by(m0, p.qkv_L, p.sh_qkv_l) : 0, pre_l0 = m0 - pre_b * p.qkv_L;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
     for (int nt = nt_begin; nt < nt_begin + nt_per; ++nt) {
+        if constexpr (HALF) {
+            if (presplit && nt * 32 >= 2 * p.qkv_C) {   // ---- V: formed untransposed, split and stored from the registers
+                f32x16 acc = split_ok ? tile64_half_rows(Wsm + (nt * 32 + fr) * LDK + fh, ah, al)
+                                      : tile64_f32_rows(p.W + (size_t)(nt * 32 + fr) * ldw + fh, a);
+                const float bcol = bias_s[nt * 32 + fr];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = acc[r] * out_scale + bcol;
+                // lane (column fr, h): acc[4 u + e] = v[key 8 u + 4 h + e][column]; head = 2 (nt & 1) + (fr >> 4), d = fr & 15
+                const int head = 2 * ((nt * 32 - 2 * p.qkv_C) >> 5) + (fr >> 4), d = fr & 15, hh = lane >> 5;
+                const int bh = pre_b * p.qkv_heads + head;
+                float mj[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) m = fmaxf(m, fabsf(acc[8 * j + r]));
+                    mj[j] = m;
+                }
+                // flags of (head, group of 16 keys j): lanes of the head are those with the same bit 4
+                int flag[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned long long big = __ballot(!(mj[j] < 32768.f)), small = __ballot(mj[j] < 0.0009765625f);
+                    const unsigned long long mine = (fr >> 4) ? 0xffff0000ffff0000ull : 0x0000ffff0000ffffull;
+                    flag[j] = ((big & mine) != 0 || (small & mine) == mine) ? 1 : 0;
+                }
+                if ((lane & 15) == 0 && hh == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        p.pre_flags[((size_t)bh * (p.qkv_L >> 4) + (pre_l0 >> 4) + j) * 2 + 1] = flag[j];
+                }
+                // slot group g of the 32-key half: keys 4 g + e (j = 0) and 16 + 4 g + e (j = 1); this lane holds g = hh and 2 + hh
+                float* vt = p.pre_vs + ((size_t)bh * p.qkv_L + (pre_l0 & ~63)) * 16;           // the 64-key tile's 4 KB
+                const int half = (pre_l0 >> 5) & 1;
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * gg + hh, u0 = gg, u1 = 2 + gg;   // rows 8 u + 4 h + e: u = gg -> keys 4 g + e, u = 2 + gg -> 16 + 4 g + e
+                    unsigned h4[4], l4[4];
+                    split_scaled_pair_f16(acc[4 * u0], acc[4 * u0 + 1], h4[0], l4[0]);
+                    split_scaled_pair_f16(acc[4 * u0 + 2], acc[4 * u0 + 3], h4[1], l4[1]);
+                    split_scaled_pair_f16(acc[4 * u1], acc[4 * u1 + 1], h4[2], l4[2]);
+                    split_scaled_pair_f16(acc[4 * u1 + 2], acc[4 * u1 + 3], h4[3], l4[3]);
+                    const int at = (half * 512 + (d * 4 + g) * 8) / 2;   // floats; hi block, the lo block 512 floats further
+                    *reinterpret_cast<u32x4*>(vt + at) = u32x4{h4[0], h4[1], h4[2], h4[3]};
+                    *reinterpret_cast<u32x4*>(vt + 512 + at) = u32x4{l4[0], l4[1], l4[2], l4[3]};
+                }
+                if (flag[0] | flag[1]) {   // (rare) the fp32 values of the flagged head's keys, [key][16]
+                    float* v32 = p.out + 2 * p.qkv_plane + ((size_t)bh * p.qkv_L + pre_l0) * 16 + d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v32[(size_t)(8 * (r >> 2) + 4 * hh + (r & 3)) * 16] = acc[r];
+                }
+                continue;
+            }
+        }
         // acc[r] = out[row m0 + (lane & 31)][column nt*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5)]
         f32x16 acc;
         if constexpr (HALF) {
@@ -1014,6 +1105,40 @@ __global__ __launch_bounds__(1024) void k_gemm_k64(const IGemmArgs p) {
         const int n = nt * 32 + oc4;
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + n);
         const unsigned long long co = coloff[n >> 2];
+        if constexpr (HALF) {
+            if (presplit && nt * 32 >= p.qkv_C) {   // ---- K: split on the way out; lane = columns oc4 .. + 3 of rows orow + 8 j
+                const int head = 2 * ((nt * 32 - p.qkv_C) >> 5) + (oc4 >> 4), d4 = oc4 & 15;
+                const int bh = pre_b * p.qkv_heads + head;
+                float4 v[4];
+                float mj[2] = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
+                    v[j].x += bv.x; v[j].y += bv.y; v[j].z += bv.z; v[j].w += bv.w;
+                    mj[j >> 1] = fmaxf(fmaxf(mj[j >> 1], fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+                    unsigned h2[2], l2[2];
+                    split_scaled_pair_f16(v[j].x, v[j].y, h2[0], l2[0]);
+                    split_scaled_pair_f16(v[j].z, v[j].w, h2[1], l2[1]);
+                    *reinterpret_cast<u32x4*>(p.pre_ks + ((size_t)bh * p.qkv_L + pre_l0 + orow + 8 * j) * 16 + d4) =
+                        u32x4{h2[0], h2[1], l2[0], l2[1]};
+                }
+                // flags of (head, group of 16 keys): rows orow + 8 j with j < 2 are the first group; the head's lanes have the same bit 2
+                const unsigned long long mine = (oc4 >> 4) ? 0xf0f0f0f0f0f0f0f0ull : 0x0f0f0f0f0f0f0f0full;
+                int flag[2];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) flag[gq] = (__ballot(!(mj[gq] < 32768.f)) & mine) != 0 ? 1 : 0;
+                if (lane == 0 || lane == 4) {
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq)
+                        p.pre_flags[((size_t)bh * (p.qkv_L >> 4) + (pre_l0 >> 4) + gq) * 2] = flag[gq];
+                }
+                if (flag[0] | flag[1]) {   // (rare) the fp32 values of the flagged head's keys
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(p.out + roff4[j] + co) = v[j];
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = *reinterpret_cast<const float4*>(stage + (orow + 8 * j) * LDO + oc4);
@@ -1417,6 +1542,11 @@ bool igemm_uses_split(const IGemmArgs& a) {
            (a.a_mode != A_CONV || a.Cin % 64 == 0) && (ks == 1 || a.chunks_per_split % 2 == 0);
 }
 
+bool gemm_k64_presplits(const IGemmArgs& a) {
+    return takes_k64_path(a) && igemm_uses_split(a) && a.st_mode == ST_QKV && a.qkv_hd == 16 && a.qkv_C == 64 && a.N == 192 &&
+           a.qkv_heads == 4 && a.M % 32 == 0 && a.qkv_L % 64 == 0 && a.act == ACT_NONE;
+}
+
 static int log2_if_pow2(long long d) {
     if (d <= 0 || (d & (d - 1))) return -1;
     int s = 0;
@@ -1441,6 +1571,8 @@ hipError_t launch_igemm(const IGemmArgs& args, hipStream_t stream) {
     if (a.a_mode == A_CONV && !a.zeros) return hipErrorInvalidValue;
     if ((long long)a.M * a.N >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element indices within an output or slab
     if (a.out2 && (a.n_split <= 0 || a.n_split % BN || a.n_split >= a.N || a.st_mode != ST_ROW)) return hipErrorInvalidValue;
+    if ((a.pre_ks || a.pre_vs || a.pre_flags) && !(a.pre_ks && a.pre_vs && a.pre_flags && gemm_k64_presplits(a)))
+        return hipErrorInvalidValue;
     if (takes_k64_path(a)) {
         // one 32-row tile per wave; fewer waves per workgroup when there are too few tiles for 256 CUs
         const int nsplit = (a.N % 64 == 0 && a.N >= 128) ? 2 : 1;

@@ -22,10 +22,10 @@ static void run(const char* name, const float* q, const float* k, const float* v
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc, FlashPre{nullptr, nullptr, nullptr});
     hipEventRecord(e0, 0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_flash_hd16<QT, ABL, PVH, QKH, KT64>), grid, dim3(256), 0, 0, q, k, v, o, nullptr, L, heads, B * heads, sc, FlashPre{nullptr, nullptr, nullptr});
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -81,6 +81,31 @@ int main(int argc, char** argv) {
                where / ((size_t)L * 64), (where / 64) % L, where % 64, a[where], b[where], bad, n);
         printf("max |fp16-halves - fp32| = %.3e  (max |out| %.3e, ratio %.2e)\n", md, mx, md / mx);
         hipFree(o2);
+    }
+    {   // K and V pre-split by their producer: the copy kernel, then the core on its output
+        float *ks, *vs, *o3;
+        int* fl;
+        hipMalloc(&ks, n * 4); hipMalloc(&vs, n * 4); hipMalloc(&o3, n * 4); hipMalloc(&fl, (size_t)B * 4 * (L / 16) * 2 * 4);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 2; ++rep) {
+            launch_presplit_kv(k, v, ks, vs, fl, B * 4, L, 0);
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; ++i) launch_attention_hd16_pre(q, ks, vs, k, v, fl, o3, B, 4, L, 0);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s %8.1f us\n", "full, K and V pre-split", ms * 100.0);
+        }
+        run<0>("full again", q, k, v, o, B, L);
+        std::vector<float> a(n), b(n);
+        hipMemcpy(a.data(), o, n * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), o3, n * 4, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0;
+        size_t diff = 0;
+        for (size_t i = 0; i < n; ++i) { md = fmax(md, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)a[i])); diff += a[i] != b[i]; }
+        printf("pre-split against in-kernel split: max difference %.3e of %.3e, %zu of %zu values differ\n", md, mx, diff, n);
     }
     run<1>("no exp2", q, k, v, o, B, L);
     run<2>("no V LDS reads", q, k, v, o, B, L);

@@ -163,6 +163,13 @@ int danra_noise_image(const float* x_dev, const int64_t* t_dev, const float* alp
  * log-sum-exp of every query's scaled scores in the exp2 domain. */
 int danra_attention_core_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, float* lse2_dev,
                              int B, int heads, int L, int head_dim, void* stream);
+/* The head_dim-16 core in the form the network's inference path runs it (modules:100-107, between the in- and out-projection
+ * of nn.MultiheadAttention): K and V are first brought to the pre-split layout the QKV projection kernels of the network
+ * write directly (fp16 halves in the order of the core's tiles, one range flag per 16 keys), then the core reads those.
+ * Same arguments and result as danra_attention_core_fwd without the log-sum-exp; head_dim 16, L a multiple of 128.
+ * Allocates a temporary buffer and waits for the stream: an entry for unit tests. */
+int danra_attention_core_presplit_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B,
+                                      int heads, int L, int head_dim, void* stream);
 /* Numerics switch (no counterpart in the reference; process-wide).  Two kernel families evaluate their fp32 products
  * on the fp16 matrix cores with every operand split in two fp16 halves (22 significant bits per operand, fp32
  * accumulation; operands outside the range where that holds are multiplied with fp32 instructions): the head_dim-16

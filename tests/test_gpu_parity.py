@@ -536,6 +536,97 @@ def test_fused_attention_blocks_equal_the_separate_kernels(cond64, dev, monkeypa
         assert rel_err(fused[b], separate[b]) < 1e-4, f"image {b}"
 
 
+def test_presplit_keys_and_values_change_no_bit(cond64, dev, monkeypatch):
+    """The QKV projections of the 64-channel blocks hand K and V to the attention core already split in fp16 halves
+    (with DANRA_PRESPLIT=0 the core splits fp32 K and V itself, tile by tile): the same halves either way, so a whole
+    forward at the benchmark's batch - the 1024-token blocks through the row-stationary GEMM, the 256-token ones through
+    the one-wave-per-16-tokens kernel - must not move by a bit; likewise single blocks at small batches, where the
+    1024-token block takes the second producer."""
+    from gpu_util import Ops
+    model, _, ops = cond64
+    B = 64
+    inp = {k: v.to(dev) for k, v in gs.variant_inputs("cond", B, 64).items()}
+    t = torch.randint(1, 1000, (B,), generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        pre = model(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
+    x0, x1 = gs.randn(31, 2, 64, 32, 32).to(dev), gs.randn(32, 3, 64, 16, 16).to(dev)
+    pre0, pre1 = ops.attention(0, x0).cpu(), ops.attention(8, x0, relu=True).cpu()
+    pre2 = ops.attention(1, x1).cpu()
+    monkeypatch.setenv("DANRA_PRESPLIT", "0")
+    other = build_model("cond", 64).to(dev)  # the same seeded weights; its engine is created under the switch
+    with torch.no_grad():
+        plain = other(inp["x"], t, inp["y"], inp["cond_img"], inp["lsm_cond"], inp["topo_cond"]).cpu()
+    assert torch.equal(pre, plain)
+    ops2 = Ops(other.hip_engine(dev))
+    assert torch.equal(ops2.attention(0, x0).cpu(), pre0)
+    assert torch.equal(ops2.attention(8, x0, relu=True).cpu(), pre1)
+    assert torch.equal(ops2.attention(1, x1).cpu(), pre2)
+
+
+@pytest.mark.parametrize("index,prefix,side,batch", [(0, "encoder.attention_layers.0", 32, 32),    # 32768 tokens: the row-stationary GEMM
+                                                     (0, "encoder.attention_layers.0", 32, 2),     # one wave per 16 tokens
+                                                     (1, "encoder.attention_layers.1", 16, 5)])
+@pytest.mark.parametrize("case", ["huge_values", "tiny_values", "huge_keys_and_values", "nonfinite_value"])
+def test_presplit_producers_flag_what_leaves_the_split_range(dev, monkeypatch, index, prefix, side, batch, case):
+    """Value and key projections scaled out of the range in which the fp16 halves hold 22 bits: the projection kernel
+    flags the groups of 16 keys concerned and writes their fp32 values beside the halves, and the core multiplies the
+    tiles that hold them with fp32 instructions.  Against the restatement, per head of the core's output (the block's
+    output projection mixes the heads: it is made a multiple of the identity).  (The scalings stay within what ONE
+    power-of-two scale per projection matrix represents: rows 1e5 below the largest keep about 19 bits.  Huge keys make
+    scores of 1e5 and a softmax no fp32 evaluation agrees on with another: that case is compared with the other form of
+    the library instead, which multiplies the same fp32 values in the same order when K and V of a head are both out of
+    range.)"""
+    from gpu_util import Ops
+    C = 64
+    q_rows, k_rows, v_rows = (slice(i * C, (i + 1) * C) for i in range(3))
+    head = lambda rows, h: slice(rows.start + 16 * h, rows.start + 16 * h + 16)  # noqa: E731
+
+    def scaled_model():
+        model = build_model("cond", 64)
+        with torch.no_grad():
+            mha = model.get_submodule(prefix).attention
+            mha.out_proj.weight.copy_(torch.eye(C))
+            mha.out_proj.bias.zero_()
+            if case == "huge_values":
+                mha.in_proj_weight[head(v_rows, 1)] *= 3e5
+                mha.in_proj_bias[head(v_rows, 1)] *= 3e5
+            elif case == "tiny_values":    # every head; brought back to order one by the output projection (whose rows are
+                mha.in_proj_weight[v_rows] *= 1e-4          # then tiny throughout and take its fp32 form): the residual
+                mha.in_proj_bias[v_rows] *= 1e-4            # would hide them
+                mha.out_proj.weight.mul_(1e4)
+            elif case == "huge_keys_and_values":
+                mha.in_proj_weight[head(k_rows, 3)] *= 1e5
+                mha.in_proj_bias[head(k_rows, 3)] *= 1e5
+                mha.in_proj_weight[head(v_rows, 3)] *= 3e5
+                mha.in_proj_bias[head(v_rows, 3)] *= 3e5
+        return model
+
+    model = scaled_model()
+    sd = state_dict_cpu(model)
+    ops = Ops(model.to(dev).hip_engine(dev))
+    x = gs.randn(700 + index + batch, batch, C, side, side)
+    if case == "nonfinite_value":
+        x[batch - 1, 7, 3, 5] = float("inf")   # LayerNorm of this token is NaN: its q, k and v are not finite
+    got = ops.attention(index, x.to(dev)).cpu()
+    if case == "huge_keys_and_values":
+        monkeypatch.setenv("DANRA_PRESPLIT", "0")
+        other = Ops(scaled_model().to(dev).hip_engine(dev))
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, other.attention(index, x.to(dev)).cpu())
+        return
+    want = cpu_ref.image_self_attention(sd, prefix, x) - x      # the block adds its input: compare the attention part
+    got = got - x
+    if case == "nonfinite_value":
+        # every query of that image meets the token's key: the image is not finite, the others are untouched
+        assert not torch.isfinite(got[batch - 1]).any()
+        assert rel_err(got[:batch - 1], want[:batch - 1]) < TOL_OP
+        return
+    assert torch.isfinite(got).all()
+    for h in range(4):
+        rows = slice(16 * h, 16 * h + 16)
+        assert rel_err(got[:, rows], want[:, rows]) < 2 * TOL_OP, (case, h)
+
+
 @pytest.mark.parametrize("T", [2, 3, 4])
 def test_shortest_sampling_chains(cond64, dev, T):
     """T = 2 is one evaluation and a noise-free update, T = 3 the first chain in which the update kernel hands a gathered

@@ -45,6 +45,18 @@ def run_core(q, k, v, dout):
     return out.cpu(), dq.cpu(), dk.cpu(), dv.cpu(), lse2.cpu()
 
 
+def run_core_presplit(q, k, v):
+    """The same core as the network's inference path runs it: K and V pre-split by their producer."""
+    lib = hip_engine.load_library()
+    B, heads, L, hd = q.shape
+    qd, kd, vd = (t.to(DEV).contiguous() for t in (q, k, v))
+    out = torch.empty((B, L, heads * hd), device=DEV)
+    _check(lib, lib.danra_attention_core_presplit_fwd(_ptr(qd), _ptr(kd), _ptr(vd), _ptr(out), B, heads, L, hd, _stream()),
+           "presplit fwd")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
 def close(got, want, tol, what):
     err = (got.double() - want.double()).abs().max().item()
     ref = want.double().abs().max().item()
@@ -76,7 +88,8 @@ def test_core_forward_and_backward_match_float64(B, heads, L, qscale):
 @pytest.mark.parametrize("case", ["huge_values_late", "huge_values_first_tile", "tiny_values", "wide_probability_range",
                                   "nonfinite_value", "huge_keys_late", "huge_queries", "tiny_keys_large_queries",
                                   "band_values_3e-3", "band_all_uniform_2^-8_2^-3"])
-def test_core_forward_value_ranges(case):
+@pytest.mark.parametrize("form", ["fp32_operands", "presplit_operands"])
+def test_core_forward_value_ranges(case, form):
     """The forward kernel multiplies K Q^T and P V on the fp16 matrix cores (operands split in fp16 halves) while every
     |K|, |V| it has staged and every scaled |Q| of the workgroup is below 2^15, and in fp32 from the first tile on that
     holds a larger (or non-finite) value.  Both forms, and the switch between them in the middle of a row, stay within
@@ -112,7 +125,12 @@ def test_core_forward_value_ranges(case):
             return torch.exp2(torch.rand(t.shape, generator=g) * 5.0 - 8.0) * torch.sign(t)
         q, k, v = band(q) * 64.0, band(k), band(v)   # scores of order one from keys in the band
     dout = torch.zeros(B, L, heads * 16)
-    out, _, _, _, lse2 = run_core(q, k, v, dout)
+    if form == "presplit_operands":
+        # (here the switch to fp32 products is made per tile of 64 keys, from the flags of its groups of 16, and a flagged
+        # group is read from the fp32 tensors while its neighbours come from the halves)
+        out = run_core_presplit(q, k, v)
+    else:
+        out, _, _, _, lse2 = run_core(q, k, v, dout)
     p = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 4.0, dim=-1)
     if case == "nonfinite_value":
         # as in fp32 arithmetic: the column of head 0, image 0 that meets the infinite value is inf (or nan where its
@@ -132,6 +150,39 @@ def test_core_forward_value_ranges(case):
             close(out[:, :, 16 * h:16 * h + 16], want[:, :, 16 * h:16 * h + 16], 1e-5, f"out, head {h}")
     else:
         close(out, want, 1e-5, "out")
+
+
+@pytest.mark.parametrize("B,heads,L", [(2, 4, 256), (3, 4, 1024), (1, 2, 4096)])
+def test_presplit_core_equals_the_core_on_fp32_operands_bit_for_bit(B, heads, L):
+    """With every value inside the split's range the two forms multiply the same halves in the same order."""
+    g = torch.Generator().manual_seed(77 + L)
+    q = torch.randn(B, heads, L, 16, generator=g)
+    k = torch.randn(B, heads, L, 16, generator=g)
+    v = torch.randn(B, heads, L, 16, generator=g) * 2 + 0.5
+    out, _, _, _, _ = run_core(q, k, v, torch.zeros(B, L, heads * 16))
+    assert torch.equal(run_core_presplit(q, k, v), out)
+
+
+def test_presplit_core_reads_single_flagged_groups_from_the_fp32_operands():
+    """Groups of 16 keys out of range here and there (K in one place, V in another, the last group of a tile, two in one
+    tile), queries in range: each tile with a flagged group is multiplied with fp32 instructions, the flagged groups from the
+    fp32 operands and their neighbours from the halves."""
+    B, heads, L = 1, 4, 512
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, heads, L, 16, generator=g)
+    k = torch.randn(B, heads, L, 16, generator=g)
+    v = torch.randn(B, heads, L, 16, generator=g)
+    v[0, 0, 16:32] *= 2e5           # one V group of tile 0
+    v[0, 1, 112:128] *= 1e-6        # a tiny group: last group of tile 1
+    k[0, 2, 200, 3] = 4e4           # one K value: group 12 of head 2 (the scores of this key dominate or vanish)
+    v[0, 3, 300:310] *= 1e5         # V of groups 18 ...
+    k[0, 3, 330:340] *= 5e4         # ... and K of group 20, both in tile 5 (groups 20 and 21), of head 3
+    q[0, 3] *= 1e-4
+    out = run_core_presplit(q, k, v)
+    p = torch.softmax(q.double() @ k.double().transpose(-1, -2) / 4.0, dim=-1)
+    want = (p @ v.double()).permute(0, 2, 1, 3).reshape(B, L, -1)
+    for h in range(heads):
+        close(out[:, :, 16 * h:16 * h + 16], want[:, :, 16 * h:16 * h + 16], 1e-5, f"out, head {h}")
 
 
 def test_core_is_deterministic_and_rejects_other_shapes():
