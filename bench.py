@@ -31,18 +31,18 @@ PROF_FLASH_ATTENTION, PROF_IGEMM = 1, 2  # danra_profile_begin kinds (include/da
 
 WORKLOADS = {
     # the benchmark configurations: unconditional 64x64, conditional 64x64 (the headline), conditional 128x128
-    "c2": dict(name="DANRA unconditional 64x64, T=1000, batch 32/GPU", size=64, batch=32, cond=False),
-    "c3": dict(name="DANRA conditional (lsm+topo+cond image+season embedding) 64x64, T=1000, batch 64/GPU", size=64,
+    "c2": dict(name="DANRA unconditional 64x64, T=1000, batch {batch}", size=64, batch=32, cond=False),
+    "c3": dict(name="DANRA conditional (lsm+topo+cond image+season embedding) 64x64, T=1000, batch {batch}", size=64,
                batch=64, cond=True),
-    "c4": dict(name="DANRA conditional 128x128, T=1000, batch 32/GPU", size=128, batch=32, cond=True),
+    "c4": dict(name="DANRA conditional 128x128, T=1000, batch {batch}", size=128, batch=32, cond=True),
     # the DDPM_clean_application variant (attention blocks with a feed-forward part); secondary workloads
-    "clean": dict(name="clean-application network, conditional (lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU",
+    "clean": dict(name="clean-application network, conditional (lsm+topo+cond image+season) 64x64, T=1000, batch {batch}",
                   size=64, batch=64, cond=True, clean=True),
     "clean_h1": dict(name="clean-application network with its configuration default of 1 attention head, conditional "
-                          "(lsm+topo+cond image+season) 64x64, T=1000, batch 64/GPU", size=64, batch=64, cond=True,
+                          "(lsm+topo+cond image+season) 64x64, T=1000, batch {batch}", size=64, batch=64, cond=True,
                      clean=True, heads=1),
     "clean_cfg": dict(name="clean-application network, season label only, classifier-free guidance 3.0 (two UNet "
-                           "evaluations per step) 64x64, T=1000, batch 64/GPU", size=64, batch=64, cond=False, clean=True,
+                           "evaluations per step) 64x64, T=1000, batch {batch}", size=64, batch=64, cond=False, clean=True,
                       labels=True, cfg_scale=3.0),
 }
 
@@ -317,7 +317,8 @@ def main():
             "dtype": "f32 (fp16 split-operand products: 22-bit operands, fp32 accumulate)",
             "data": "synthetic (seeded inputs, deterministic random-init weights, in-kernel Philox noise)" +
                     (" REHEARSAL: ranks share GPUs, gloo backend, not a measurement" if rehearsal else ""),
-            "config": {"workload": w["name"], "timesteps": T, "batch_per_gpu": B, "global_batch": world * B,
+            "config": {"workload": w["name"].format(batch=f"{B}/GPU x {world} GPU{'s' if world > 1 else ''} = global batch {world * B}"),
+                       "timesteps": T, "batch_per_gpu": B, "global_batch": world * B,
                        "image": f"{w['size']}x{w['size']}", "parallelism": f"batch-sharded x{world}, weights broadcast "
                        f"once ({sent} bytes), no collective in the loop"},
             "unet_ms": 1e3 * elapsed / args.steps / (T - 1),

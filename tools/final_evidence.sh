@@ -16,6 +16,8 @@ for w in clean clean_cfg clean_h1; do
 done
 DANRA_BENCH_REHEARSAL=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --timesteps 200 --no-cpu-baseline > "$OUT/rehearsal.log" 2>&1
 grep -o '{"metric.*' "$OUT/rehearsal.log" > "$OUT/bench_rehearsal_2rank.json"
+DANRA_BENCH_REHEARSAL=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --workload c4 --steps 1 --warmup 1 --timesteps 100 --no-cpu-baseline --no-strict-fp32 > "$OUT/rehearsal_c4.log" 2>&1
+grep -o '{"metric.*' "$OUT/rehearsal_c4.log" > "$OUT/bench_rehearsal_2rank_c4.json"
 bash tools/pmc_traffic.sh > "$OUT/pmc_traffic.log" 2>&1
 bash tools/pmc_sq.sh > "$OUT/pmc_sq.log" 2>&1
 echo done
