@@ -1364,6 +1364,30 @@ int danra_attention_core_bwd(const float* q, const float* k, const float* v, con
     return DANRA_OK;
 }
 
+int danra_attention_small_supported(int B, int heads, int L, int head_dim) {
+    return attention_small_train_supported(B, heads, L, head_dim) ? 1 : 0;
+}
+
+int danra_attention_small_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L, int head_dim,
+                              void* stream) {
+    if (!q || !k || !v || !out) return fail(DANRA_EINVAL, "null argument");
+    if (!attention_small_train_supported(B, heads, L, head_dim))
+        return fail(DANRA_EINVAL, "B=%d heads=%d L=%d head_dim=%d: the short-sequence core takes 1..64 tokens, head_dim a multiple of 4 "
+                    "up to 128 and at most 2048 values per head", B, heads, L, head_dim);
+    HIP_TRY(launch_attention_small_fwd(q, k, v, out, B, heads, L, head_dim, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_attention_small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv,
+                              int B, int heads, int L, int head_dim, void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv) return fail(DANRA_EINVAL, "null argument");
+    if (!attention_small_train_supported(B, heads, L, head_dim))
+        return fail(DANRA_EINVAL, "B=%d heads=%d L=%d head_dim=%d: not a shape of the short-sequence core (danra_attention_small_supported)",
+                    B, heads, L, head_dim);
+    HIP_TRY(launch_attention_small_bwd(q, k, v, dout, dq, dk, dv, B, heads, L, head_dim, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                               float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
                               float momentum, int relu, void* stream) {

@@ -119,6 +119,13 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
 
 // ---------------------------------------------------------------- attention
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
+// softmax(q k^T / sqrt(hd)) v of the short-sequence attention blocks for training (kernels_attn_small_train.hip): q, k, v,
+// dq, dk, dv [B*heads][L][hd]; out, dout [B][L][heads*hd].
+bool attention_small_train_supported(int B, int heads, int L, int hd);
+hipError_t launch_attention_small_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L, int hd,
+                                      hipStream_t stream);
+hipError_t launch_attention_small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                                      float* dv, int B, int heads, int L, int hd, hipStream_t stream);
 // K, V [n_bh][L][16] -> the pre-split form of the head_dim-16 core (ks, vs: as many bytes as k, v; flags: 2 * n_bh * L / 16
 // ints), and that core on it; k32 / v32 are read only where a flag is set (kernels_attn.hip, k_flash_hd16 PRE).
 hipError_t launch_presplit_kv(const float* k, const float* v, float* ks, float* vs, int* flags, int n_bh, int L,

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_attention_core_presplit_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_fp32_products": (ctypes.c_int, [ctypes.c_int]),
+    "danra_attention_small_supported": (ctypes.c_int, [ctypes.c_int] * 4),
+    "danra_attention_small_fwd": (ctypes.c_int, [_P] * 4 + [ctypes.c_int] * 4 + [_P]),
+    "danra_attention_small_bwd": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
     "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -264,6 +267,48 @@ class _AttentionCoreHD16(torch.autograd.Function):
         return dqkv
 
 
+class _AttentionCoreSmall(torch.autograd.Function):
+    """softmax(q k^T / sqrt(head_dim)) v per head for the short sequences of the deep levels (at most 64 tokens, head_dim up
+    to 128), forward and backward in libdanra_hip.so (danra_attention_small_fwd / _bwd): one workgroup per (image, head),
+    the backward forms the probabilities again instead of keeping them.
+    qkv: [3, B, heads, L, head_dim] contiguous -> tokens [B, L, heads*head_dim]."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, qkv):
+        lib = load_library()
+        qkv = qkv.contiguous()
+        _, B, heads, L, hd = qkv.shape
+        out = torch.empty((B, L, heads * hd), device=qkv.device, dtype=torch.float32)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_small_fwd(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(out), B, heads, L, hd,
+                                                      _stream()), "danra_attention_small_fwd")
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        lib = load_library()
+        (qkv,) = ctx.saved_tensors
+        _, B, heads, L, hd = qkv.shape
+        dout = _f32(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_small_bwd(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(dout), _ptr(dqkv[0]),
+                                                      _ptr(dqkv[1]), _ptr(dqkv[2]), B, heads, L, hd, _stream()),
+                   "danra_attention_small_bwd")
+        return dqkv
+
+
+def attention_small_supported(tokens, n_heads):
+    """True when the differentiable self-attention of [B, L, C] `tokens` can run its core in the native library's
+    short-sequence kernels: a CUDA tensor (float32; half precision under autocast), at most 64 tokens."""
+    B, L, C = tokens.shape
+    return (native_training_kernels and tokens.is_cuda and _native_dtype(tokens) and C % n_heads == 0
+            and bool(load_library().danra_attention_small_supported(B, n_heads, L, C // n_heads)))
+
+
 def _native_dtype(x):
     """float32 always; under autocast (the reference's training loop runs its forward inside `autocast()`,
     training_DANRA_conditional.py:962-971) also the half-precision tensors autocast hands over: the native kernels
@@ -368,14 +413,16 @@ def token_linear(x, weight, bias):
 def differentiable_self_attention(mha, tokens):
     """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module: the
     two projections through token_linear, the scaled-dot-product core in the native library where it has the shape
-    (attention_core_supported: head_dim 16, the 64-channel levels) and torch's fused scaled_dot_product_attention
-    otherwise."""
+    (attention_core_supported: head_dim 16, the 64-channel levels; attention_small_supported: the short sequences of the
+    deep levels) and torch's fused scaled_dot_product_attention otherwise."""
     B, L, C = tokens.shape
     heads = mha.num_heads
     qkv = token_linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
     qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
     if attention_core_supported(tokens, heads):
         attended = _AttentionCoreHD16.apply(qkv)  # (made contiguous and float32 by the core)
+    elif attention_small_supported(tokens, heads):
+        attended = _AttentionCoreSmall.apply(qkv)
     else:
         attended = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         attended = attended.permute(0, 2, 1, 3).reshape(B, L, C)
@@ -741,8 +788,8 @@ def conv_transpose2d(convt, x):
 def conv2d(conv, x):
     """``conv(x)`` for an nn.Conv2d.  A 3x3, stride-1, padding-1, ungrouped convolution on a 4-D CUDA tensor (float32; half
     precision under autocast) with gradients enabled - the training step - runs forward and backward in the native library
-    where it has the shape (danra_conv3x3_train_supported); the bias, if any, is added by torch.  Everything else is the
-    module itself."""
+    where it has the shape (danra_conv3x3_train_supported); the bias, if any, is added by torch.  So does the stride-2 form
+    of that convolution and the 1x1 stride-2 shortcut beside it.  Everything else is the module itself."""
     if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
             and type(conv) is torch.nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and _native_dtype(x)
@@ -750,6 +797,19 @@ def conv2d(conv, x):
         B, Cin, H, W = x.shape
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)
+            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    # 3x3, stride 2, padding 1 on even sides (the first convolution of a down-sampling BasicBlock): the stride-1 kernels
+    # evaluated everywhere, every second row and column kept - four times the products of three small layers (3 % of a
+    # step's), in exchange for forward, data gradient and weight gradient in the library; autograd scatters dy back into
+    # the full map
+    if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
+            and type(conv) is torch.nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and _native_dtype(x)
+            and conv.weight.dtype == torch.float32 and (x.requires_grad or conv.weight.requires_grad)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+        B, Cin, H, W = x.shape
+        if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
+            y = _Conv3x3Train.apply(x, conv.weight)[:, :, ::2, ::2]
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
     if (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and _pointwise_ok(x, conv.weight)):

@@ -185,6 +185,15 @@ int danra_attention_core_bwd(const float* q_dev, const float* k_dev, const float
                              const float* dout_dev, const float* lse2_dev, float* dq_dev, float* dk_dev, float* dv_dev,
                              float* delta_dev, int B, int heads, int L, int head_dim, void* stream);
 
+/* The scaled-dot-product core of the short-sequence attention blocks in a training step (the deep levels: nn.MultiheadAttention
+ * between its in- and out-projection, modules:100-107, at 64 / 16 / 4 tokens with head_dim 32 / 64 / 128): softmax(q k^T /
+ * sqrt(head_dim)) v per (image, head), forward and the gradients of q, k and v.  q, k, v, dq, dk, dv [B*heads][L][head_dim];
+ * out, dout [B][L][heads*head_dim] (token order).  1 <= L <= 64, head_dim a multiple of 4 up to 128, L * head_dim <= 2048. */
+int danra_attention_small_supported(int B, int heads, int L, int head_dim);
+int danra_attention_small_fwd(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int heads, int L,
+                              int head_dim, void* stream);
+int danra_attention_small_bwd(const float* q_dev, const float* k_dev, const float* v_dev, const float* dout_dev, float* dq_dev,
+                              float* dk_dev, float* dv_dev, int B, int heads, int L, int head_dim, void* stream);
 /* nn.BatchNorm2d in TRAIN mode (the encoder's bn1 and the BasicBlocks' bn1 / bn2 / downsample.1 after model.train(),
  * training_DANRA_conditional.py:517; modules_DANRA_conditional.py:271 and torchvision's BasicBlock.forward): batch
  * statistics per channel over (B, H, W), y = (x - mean) / sqrt(var_biased + eps) * gamma + beta, optionally followed by the

@@ -617,19 +617,21 @@ def native_call_counters(monkeypatch):
              "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd", "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
-             "danra_tokens_to_nchw_add")
+             "danra_tokens_to_nchw_add", "danra_attention_small_fwd", "danra_attention_small_bwd")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
 # the conditional network: 4 attention blocks at 64 channels (core forward and backward, and the weight gradients of their
 # two projections); bn1 + 8 blocks x 2 + 3 shortcut norms, the second norm of every block fused with the shortcut add and the ReLU; 4 decoder blocks x 2 InstanceNorms + the final block's first
-# (its second is an Identity); the 3x3 stride-1 convolutions: 4 + 3 + 3 + 3 in the BasicBlocks (the first convolution of
-# layers 2-4 has stride 2) and the four decoder blocks' (the final block's has one output channel), each in three directions
-EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_batchnorm_train_fwd": 12,
+# (its second is an Identity); the 3x3 convolutions: 4 + 4 + 4 + 4 in the BasicBlocks (the first convolution of layers 2-4
+# has stride 2 and goes through the stride-1 kernels) and the four decoder blocks' (the final block's has one output
+# channel), each in three directions; the cores of the five attention blocks at 128 channels and more
+EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_attention_small_fwd": 5,
+                         "danra_attention_small_bwd": 5, "danra_batchnorm_train_fwd": 12,
                          "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
-                         "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
-                         "danra_conv3x3_train_wgrad": 17,
+                         "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 20, "danra_conv3x3_train_dgrad": 20,
+                         "danra_conv3x3_train_wgrad": 20,
                          # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
                          "danra_pointwise_train_fwd": 8, "danra_pointwise_train_dgrad": 8, "danra_pointwise_train_wgrad": 8,
                          # entry and exit of the nine attention blocks
@@ -788,3 +790,77 @@ def test_instance_norm_kernels_match_torch(shape):
     yg.backward(dy.to(DEV))
     close(yg.detach().cpu(), yr.detach(), 1e-5, "output")
     close(xg.grad.cpu(), xr.grad, 1e-5, "input gradient")
+
+
+def small_reference(q, k, v, dout):
+    """softmax(q k^T / sqrt(hd)) v and its gradients in float64 (what nn.MultiheadAttention evaluates between its
+    projections, modules_DANRA_conditional.py:100-107), out in token order [B, L, heads*hd]."""
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    B, heads, L, hd = q.shape
+    p = torch.softmax(qd @ kd.transpose(-1, -2) / hd ** 0.5, dim=-1)
+    out = (p @ vd).permute(0, 2, 1, 3).reshape(B, L, heads * hd)
+    out.backward(dout.double())
+    return out.detach(), qd.grad, kd.grad, vd.grad
+
+
+@pytest.mark.parametrize("B,heads,L,hd,qscale", [
+    (3, 4, 64, 32, 1.0),     # the 8x8 level of a 64x64 input
+    (5, 4, 16, 64, 1.0),     # 4x4
+    (7, 4, 4, 128, 1.0),     # 2x2
+    (2, 2, 64, 32, 6.0),     # peaked rows
+    (2, 1, 16, 128, 1.0),    # one head of 128
+    (1, 4, 1, 64, 1.0),      # a single token: every probability is one
+    (32, 4, 64, 32, 1.0),    # a training batch
+])
+def test_short_sequence_core_forward_and_backward_match_float64(B, heads, L, hd, qscale):
+    lib = hip_engine.load_library()
+    assert lib.danra_attention_small_supported(B, heads, L, hd)
+    g = torch.Generator().manual_seed(L * 100 + hd)
+    q = torch.randn(B, heads, L, hd, generator=g) * qscale
+    k = torch.randn(B, heads, L, hd, generator=g)
+    v = torch.randn(B, heads, L, hd, generator=g) * 2 + 0.5
+    dout = torch.randn(B, L, heads * hd, generator=g)
+    qd, kd, vd, dd = (t.to(DEV).contiguous() for t in (q, k, v, dout))
+    out = torch.empty((B, L, heads * hd), device=DEV)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    _check(lib, lib.danra_attention_small_fwd(_ptr(qd), _ptr(kd), _ptr(vd), _ptr(out), B, heads, L, hd, _stream()), "fwd")
+    _check(lib, lib.danra_attention_small_bwd(_ptr(qd), _ptr(kd), _ptr(vd), _ptr(dd), _ptr(dq), _ptr(dk), _ptr(dv), B, heads, L, hd,
+                                              _stream()), "bwd")
+    torch.cuda.synchronize()
+    want_out, want_dq, want_dk, want_dv = small_reference(q, k, v, dout)
+    close(out.cpu(), want_out, 1e-5, "out")
+    close(dv.cpu(), want_dv, 1e-5, "dv")
+    close(dq.cpu(), want_dq, 1e-5, "dq")
+    close(dk.cpu(), want_dk, 1e-5, "dk")
+
+
+def test_short_sequence_core_refuses_other_shapes_and_runs_in_the_attention_block():
+    lib = hip_engine.load_library()
+    for B, heads, L, hd in [(2, 4, 128, 16), (2, 4, 64, 64), (2, 4, 16, 130), (0, 4, 16, 64), (2, 4, 16, 6)]:
+        assert not lib.danra_attention_small_supported(B, heads, L, hd), (B, heads, L, hd)
+    x = torch.zeros(16, device=DEV)
+    rc = lib.danra_attention_small_fwd(_ptr(x), _ptr(x), _ptr(x), _ptr(x), 2, 4, 128, 16, _stream())
+    assert rc != 0 and b"short-sequence core" in lib.danra_last_error()
+    # through the module hook: nn.MultiheadAttention of a deep level against torch's own evaluation of the module
+    torch.manual_seed(3)
+    mha = torch.nn.MultiheadAttention(128, 4, batch_first=True).to(DEV)
+    tokens = torch.randn(6, 64, 128, device=DEV, requires_grad=True)
+    calls = []
+    real = hip_engine._AttentionCoreSmall.apply
+    try:
+        hip_engine._AttentionCoreSmall.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        got = hip_engine.differentiable_self_attention(mha, tokens)
+    finally:
+        hip_engine._AttentionCoreSmall.apply = real
+    assert calls, "the native core did not run"
+    g = torch.randn_like(got)
+    got.backward(g)
+    got_grads = [tokens.grad.clone()] + [p.grad.clone() for p in mha.parameters()]
+    tokens.grad = None
+    mha.zero_grad()
+    want = mha(tokens, tokens, tokens, need_weights=False)[0]
+    want.backward(g)
+    want_grads = [tokens.grad] + [p.grad for p in mha.parameters()]
+    close(got.detach().cpu(), want.detach().cpu(), 2e-5, "block output")
+    for a, b in zip(got_grads, want_grads):
+        close(a.cpu(), b.cpu(), 5e-5, "gradient")

@@ -105,9 +105,11 @@ def test_conv2d_function_equals_the_torch_module(monkeypatch):
     del calls[:]
     with torch.no_grad():
         hip_engine.conv2d(conv, x)                                    # no gradient: the module
-    hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 1).to(DEV), x)   # stride 2: the module
+    hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 0).to(DEV), x)   # no padding: the module
     hip_engine.conv2d(torch.nn.Conv2d(128, 1, 3, 1, 1).to(DEV), x)    # one output channel: the module
     assert calls == []
+    hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 1).to(DEV), x)   # stride 2, padding 1: the stride-1 kernel, subsampled
+    assert calls == ["danra_conv3x3_train_fwd"]
 
 
 # the 1x1 stride-2 shortcut convolutions (kind 0) and the kernel-2 stride-2 transposed convolutions (kind 1) of the 64x64
@@ -193,3 +195,32 @@ def test_pointwise_modules_equal_torch(monkeypatch):
     with torch.no_grad():
         hip_engine.conv_transpose2d(torch.nn.ConvTranspose2d(64, 64, 2, 2).to(DEV), x)  # no gradient: the module
     assert calls == []
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 64, 128, 16, 16), (2, 128, 256, 8, 8), (5, 256, 512, 4, 4), (32, 64, 128, 16, 16)])
+def test_stride_two_convolution_through_the_module_hook(B, Cin, Cout, H, W):
+    """hip_engine.conv2d on the first convolution of a down-sampling BasicBlock (3x3, stride 2, padding 1; torchvision
+    BasicBlock.conv1 under modules_DANRA_conditional.py:285-303): the library's stride-1 kernels evaluated everywhere with
+    every second row and column kept, forward, data gradient and weight gradient against float64 conv2d."""
+    g = torch.Generator().manual_seed(B + Cin)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, stride=2, padding=1, bias=False).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5))
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g).to(DEV)
+    calls = []
+    real = hip_engine._Conv3x3Train.apply
+    try:
+        hip_engine._Conv3x3Train.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        y = hip_engine.conv2d(conv, x)
+    finally:
+        hip_engine._Conv3x3Train.apply = real
+    assert calls, "the native kernels did not run"
+    y.backward(dy)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    wd = conv.weight.detach().double().cpu().requires_grad_(True)
+    want = torch.nn.functional.conv2d(xd, wd, None, 2, 1)
+    want.backward(dy.double().cpu())
+    close(y.detach().cpu(), want.detach(), "forward")
+    close(x.grad.cpu(), xd.grad, "data gradient")
+    close(conv.weight.grad.cpu(), wd.grad, "weight gradient")
