@@ -334,8 +334,9 @@ def main():
             if args.roofline_kernel == "igemm":
                 exec_fp16 = 3.0 * kern_split
                 exec_fp32 = kern_exec - exec_fp16
-                name = ("k_igemm family (implicit GEMM behind every convolution, transposed convolution and projection, with "
-                        "its split-K reduction kernels)")
+                name = ("k_igemm family (the implicit GEMMs behind every convolution, transposed convolution and projection: "
+                        "k_igemm with its split-K reduction kernels, k_gemm_k64, and the window-staged convolution kernels "
+                        "k_conv_win and k_conv8s2)")
             else:
                 hd16 = w.get("heads", 4) == 4
                 exec_fp16 = kern_exec if hd16 else 0.0

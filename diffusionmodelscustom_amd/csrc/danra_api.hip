@@ -1526,6 +1526,38 @@ int danra_conv3x3_train_wgrad(const float* x, const float* dy, float* dw, int B,
     return DANRA_OK;
 }
 
+int danra_conv3x3_c1_train_supported(int B, int Cin, int H, int W) { return conv_c1_train_supported(B, Cin, H, W) ? 1 : 0; }
+
+size_t danra_conv3x3_c1_train_workspace(int B, int Cin, int H, int W) { return conv_c1_train_workspace_floats(B, Cin, H, W) * sizeof(float); }
+
+static int conv_c1_check(const void* a, const void* b, const void* c, int B, int Cin, int H, int W) {
+    if (!a || !b || !c) return fail(DANRA_EINVAL, "null argument");
+    if (!conv_c1_train_supported(B, Cin, H, W))
+        return fail(DANRA_EINVAL, "B=%d Cin=%d H=%d W=%d: not a shape of the one-output-channel convolution kernels "
+                    "(danra_conv3x3_c1_train_supported)", B, Cin, H, W);
+    return DANRA_OK;
+}
+
+int danra_conv3x3_c1_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int H, int W, void* stream) {
+    RC_TRY(conv_c1_check(x, w, y, B, Cin, H, W));
+    HIP_TRY(launch_conv_c1_train_fwd(x, w, y, B, Cin, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv3x3_c1_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, void* stream) {
+    RC_TRY(conv_c1_check(dy, w, dx, B, Cin, H, W));
+    HIP_TRY(launch_conv_c1_train_dgrad(dy, w, dx, B, Cin, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv3x3_c1_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, void* workspace,
+                                 void* stream) {
+    RC_TRY(conv_c1_check(x, dy, dw, B, Cin, H, W));
+    if (!workspace) return fail(DANRA_EINVAL, "null workspace");
+    HIP_TRY(launch_conv_c1_train_wgrad(x, dy, dw, B, Cin, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_ln_tokens_supported(int B, int C, int L) { return ln_tokens_supported(B, C, L) ? 1 : 0; }
 
 size_t danra_ln_tokens_workspace(int B, int C, int L) { return ln_tokens_workspace_floats(B, C, L) * sizeof(float); }

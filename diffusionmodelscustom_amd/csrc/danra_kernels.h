@@ -119,6 +119,14 @@ hipError_t launch_stem_x(const float* x, const float* Wt, int ldw, const float* 
 
 // ---------------------------------------------------------------- attention
 // q,k,v: [B*heads][L][hd]; out tokens [B][L][heads*hd] at column head*hd.
+// The 3x3 stride-1 padding-1 convolution to ONE output channel in a training step, NCHW fp32 (kernels_conv_c1_train.hip):
+// x, dx [B][Cin][H][W]; w, dw [1][Cin][3][3]; y, dy [B][1][H][W]; workspace: conv_c1_train_workspace_floats floats.
+bool conv_c1_train_supported(int B, int Cin, int H, int W);
+size_t conv_c1_train_workspace_floats(int B, int Cin, int H, int W);
+hipError_t launch_conv_c1_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int H, int W, hipStream_t stream);
+hipError_t launch_conv_c1_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, hipStream_t stream);
+hipError_t launch_conv_c1_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, float* workspace,
+                                      hipStream_t stream);
 // softmax(q k^T / sqrt(hd)) v of the short-sequence attention blocks for training (kernels_attn_small_train.hip): q, k, v,
 // dq, dk, dv [B*heads][L][hd]; out, dout [B][L][heads*hd].
 bool attention_small_train_supported(int B, int heads, int L, int hd);

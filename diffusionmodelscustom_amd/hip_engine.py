@@ -64,6 +64,11 @@ _SIGNATURES = {
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_attention_core_presplit_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_fp32_products": (ctypes.c_int, [ctypes.c_int]),
+    "danra_conv3x3_c1_train_supported": (ctypes.c_int, [ctypes.c_int] * 4),
+    "danra_conv3x3_c1_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "danra_conv3x3_c1_train_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
+    "danra_conv3x3_c1_train_dgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
+    "danra_conv3x3_c1_train_wgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P, _P]),
     "danra_attention_small_supported": (ctypes.c_int, [ctypes.c_int] * 4),
     "danra_attention_small_fwd": (ctypes.c_int, [_P] * 4 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_small_bwd": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
@@ -630,6 +635,46 @@ class _Conv3x3Train(torch.autograd.Function):
         return dx, dw
 
 
+class _Conv3x3C1Train(torch.autograd.Function):
+    """torch.nn.functional.conv2d(x, weight, None, stride=1, padding=1) for a [1][Cin][3][3] weight (the network's last
+    convolution) on a contiguous NCHW fp32 CUDA tensor: forward, data gradient and weight gradient in libdanra_hip.so
+    (danra_conv3x3_c1_train_fwd / _dgrad / _wgrad)."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight):
+        lib = load_library()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        y = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_conv3x3_c1_train_fwd(_ptr(x), _ptr(weight), _ptr(y), B, Cin, H, W, _stream()),
+                   "danra_conv3x3_c1_train_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        dy = _f32(dy, "dy")
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(lib, lib.danra_conv3x3_c1_train_dgrad(_ptr(dy), _ptr(weight), _ptr(dx), B, Cin, H, W, _stream()),
+                       "danra_conv3x3_c1_train_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                ws = torch.empty(max(lib.danra_conv3x3_c1_train_workspace(B, Cin, H, W) // 4, 1), device=x.device, dtype=torch.float32)
+                _check(lib, lib.danra_conv3x3_c1_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, H, W, _ptr(ws), _stream()),
+                       "danra_conv3x3_c1_train_wgrad")
+        return dx, dw
+
+
 class _LNTokens(torch.autograd.Function):
     """x [B, C, H, W] -> LayerNorm_C(x.view(B, C, H*W).transpose(1, 2)) as [B, H*W, C]: the entry of an attention block,
     forward and backward as one kernel each in libdanra_hip.so (danra_ln_tokens_fwd / _bwd): no transposed copy of the map."""
@@ -797,6 +842,9 @@ def conv2d(conv, x):
         B, Cin, H, W = x.shape
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)
+            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+        if conv.out_channels == 1 and load_library().danra_conv3x3_c1_train_supported(B, Cin, H, W):   # the network's last convolution
+            y = _Conv3x3C1Train.apply(x, conv.weight)
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
     # 3x3, stride 2, padding 1 on even sides (the first convolution of a down-sampling BasicBlock): the stride-1 kernels
     # evaluated everywhere, every second row and column kept - four times the products of three small layers (3 % of a

@@ -262,6 +262,16 @@ int danra_conv3x3_train_dgrad(const float* dy_dev, const float* w_dev, float* dx
 int danra_conv3x3_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
                               void* workspace_dev, void* stream);
 
+/* The network's last convolution in a training step: 3x3, stride 1, padding 1, Cin channels -> one output channel
+ * (modules:415-416 with last_layer: nn.Conv2d(64, 1, 3, padding=1)), on contiguous NCHW fp32 tensors, forward, data gradient
+ * and weight gradient (the bias is torch's): x, dx [B][Cin][H][W]; w, dw [1][Cin][3][3]; y, dy [B][1][H][W].
+ * workspace (weight gradient only): danra_conv3x3_c1_train_workspace(...) bytes of device memory. */
+int danra_conv3x3_c1_train_supported(int B, int Cin, int H, int W);
+size_t danra_conv3x3_c1_train_workspace(int B, int Cin, int H, int W);
+int danra_conv3x3_c1_train_fwd(const float* x_dev, const float* w_dev, float* y_dev, int B, int Cin, int H, int W, void* stream);
+int danra_conv3x3_c1_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int H, int W, void* stream);
+int danra_conv3x3_c1_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int H, int W,
+                                 void* workspace, void* stream);
 /* Entry and exit of ImageSelfAttention.forward (modules_DANRA_conditional.py:93-110) in the training step, on the NCHW map the
  * block receives and returns (L = H*W tokens of C channels):
  *   danra_ln_tokens_fwd : normed[b][l][c] = LayerNorm_C(x[b][.][l])[c] * gamma[c] + beta[c]   (x.view(B, C, L).swapaxes(1, 2)

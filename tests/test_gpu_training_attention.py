@@ -617,7 +617,8 @@ def native_call_counters(monkeypatch):
              "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd", "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
-             "danra_tokens_to_nchw_add", "danra_attention_small_fwd", "danra_attention_small_bwd")
+             "danra_tokens_to_nchw_add", "danra_attention_small_fwd", "danra_attention_small_bwd",
+             "danra_conv3x3_c1_train_fwd", "danra_conv3x3_c1_train_dgrad", "danra_conv3x3_c1_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
@@ -625,8 +626,9 @@ def native_call_counters(monkeypatch):
 # two projections); bn1 + 8 blocks x 2 + 3 shortcut norms, the second norm of every block fused with the shortcut add and the ReLU; 4 decoder blocks x 2 InstanceNorms + the final block's first
 # (its second is an Identity); the 3x3 convolutions: 4 + 4 + 4 + 4 in the BasicBlocks (the first convolution of layers 2-4
 # has stride 2 and goes through the stride-1 kernels) and the four decoder blocks' (the final block's has one output
-# channel), each in three directions; the cores of the five attention blocks at 128 channels and more
-EXPECTED_NATIVE_CALLS = {"danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_attention_small_fwd": 5,
+# channel and kernels of its own), each in three directions; the cores of the five attention blocks at 128 channels and more
+EXPECTED_NATIVE_CALLS = {"danra_conv3x3_c1_train_fwd": 1, "danra_conv3x3_c1_train_dgrad": 1, "danra_conv3x3_c1_train_wgrad": 1,
+                         "danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_attention_small_fwd": 5,
                          "danra_attention_small_bwd": 5, "danra_batchnorm_train_fwd": 12,
                          "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,

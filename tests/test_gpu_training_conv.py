@@ -106,7 +106,7 @@ def test_conv2d_function_equals_the_torch_module(monkeypatch):
     with torch.no_grad():
         hip_engine.conv2d(conv, x)                                    # no gradient: the module
     hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 0).to(DEV), x)   # no padding: the module
-    hip_engine.conv2d(torch.nn.Conv2d(128, 1, 3, 1, 1).to(DEV), x)    # one output channel: the module
+    hip_engine.conv2d(torch.nn.Conv2d(128, 32, 3, 1, 1).to(DEV), x)   # 32 output channels: the module
     assert calls == []
     hip_engine.conv2d(torch.nn.Conv2d(128, 64, 3, 2, 1).to(DEV), x)   # stride 2, padding 1: the stride-1 kernel, subsampled
     assert calls == ["danra_conv3x3_train_fwd"]
@@ -224,3 +224,50 @@ def test_stride_two_convolution_through_the_module_hook(B, Cin, Cout, H, W):
     close(y.detach().cpu(), want.detach(), "forward")
     close(x.grad.cpu(), xd.grad, "data gradient")
     close(conv.weight.grad.cpu(), wd.grad, "weight gradient")
+
+
+@pytest.mark.parametrize("B,Cin,H,W", [(3, 64, 64, 64), (2, 64, 128, 128), (5, 64, 16, 16), (32, 64, 64, 64), (2, 32, 7, 13), (1, 3, 1, 1)])
+def test_one_output_channel_convolution_matches_float64(B, Cin, H, W):
+    """The network's last convolution (nn.Conv2d(64, 1, 3, padding=1), modules_DANRA_conditional.py:415-416 with
+    last_layer) in the library, forward, data gradient and weight gradient, against float64 conv2d; then through the
+    module hook with the bias."""
+    lib = hip_engine.load_library()
+    assert lib.danra_conv3x3_c1_train_supported(B, Cin, H, W)
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(1, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(DEV)
+    dy = torch.randn(B, 1, H, W, generator=g).to(DEV)
+    y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+    ws = torch.empty(max(lib.danra_conv3x3_c1_train_workspace(B, Cin, H, W) // 4, 1), device=DEV)
+    _check(lib, lib.danra_conv3x3_c1_train_fwd(_ptr(x), _ptr(w), _ptr(y), B, Cin, H, W, _stream()), "fwd")
+    _check(lib, lib.danra_conv3x3_c1_train_dgrad(_ptr(dy), _ptr(w), _ptr(dx), B, Cin, H, W, _stream()), "dgrad")
+    _check(lib, lib.danra_conv3x3_c1_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, H, W, _ptr(ws), _stream()), "wgrad")
+    torch.cuda.synchronize()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    want = torch.nn.functional.conv2d(xd, wd, None, 1, 1)
+    want.backward(dy.double().cpu())
+    close(y.cpu(), want.detach(), "forward")
+    close(dx.cpu(), xd.grad, "data gradient")
+    close(dw.cpu(), wd.grad, "weight gradient")
+    dw2 = torch.empty_like(w)
+    _check(lib, lib.danra_conv3x3_c1_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw2), B, Cin, H, W, _ptr(ws), _stream()), "wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "weight gradient: two calls differ"
+    # the module hook
+    conv = torch.nn.Conv2d(Cin, 1, 3, 1, 1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xr = x.clone().requires_grad_(True)
+    calls = []
+    real = hip_engine._Conv3x3C1Train.apply
+    try:
+        hip_engine._Conv3x3C1Train.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        out = hip_engine.conv2d(conv, xr)
+    finally:
+        hip_engine._Conv3x3C1Train.apply = real
+    assert calls, "the native kernels did not run"
+    out.backward(dy)
+    close(out.detach().cpu(), want.detach() + conv.bias.detach().double().cpu().view(1, 1, 1, 1), "module output")
+    close(xr.grad.cpu(), xd.grad, "module data gradient")
+    close(conv.weight.grad.cpu(), wd.grad, "module weight gradient")
+    close(conv.bias.grad.cpu(), dy.double().cpu().sum().view(1), "module bias gradient")

@@ -45,7 +45,7 @@ def main():
             flash[k[1]] = {"read_bytes": 2 * f * 1024, "write_bytes": w * 1024}
     if len(sys.argv) > 2:
         # per kernel family, as bench.py's roofline object averages it: HBM bytes over all launches / launches
-        families = {"igemm": ("k_igemm", "k_gemm_k64", "k_splitk_epilogue"), "flash": ("k_flash_hd16", "k_flash_wide")}
+        families = {"igemm": ("k_igemm", "k_gemm_k64", "k_splitk_epilogue", "k_conv_win", "k_conv8s2"), "flash": ("k_flash_hd16", "k_flash_wide")}
         out = {}
         for fam, prefixes in families.items():
             total, launches = 0.0, 0
