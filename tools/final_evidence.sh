@@ -2,14 +2,19 @@
 # Runs on the GPU box (via gpurun): everything profiles/ keeps for one library build, in one call - the full GPU test
 # log, the bench lines of every workload with the kernel summary and timeline of the default one, the 2-rank
 # rehearsal line, and the counter passes.  Results land under gpurun_out/final/ (and gpurun_out/refresh, pmc, pmc_sq).
+#   STAGE=1: tests, bench lines of c3 / c2 / c4 with kernel summary and timeline; STAGE=2: the rest (default: both; one
+#   gpurun call is limited to 20 minutes)
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 cd "$ROOT"
+if [ "${STAGE:-1}" = 1 ] || [ -z "${STAGE:-}" ]; then
 timeout -k 10 900 python3 -u -m pytest tests -m gpu -v --timeout 180 --timeout-method thread > "$OUT/gpu_tests_full.txt" 2>&1 || echo "GPU TESTS FAILED"
 tail -1 "$OUT/gpu_tests_full.txt"
 bash tools/refresh_profiles.sh > "$OUT/refresh.log" 2>&1
+fi
+if [ "${STAGE:-}" = 1 ]; then echo done stage 1; exit 0; fi
 for w in clean clean_cfg clean_h1; do
     timeout -k 10 400 python3 bench.py --workload $w > "$OUT/bench_$w.log" 2>&1
     grep -o '{"metric.*' "$OUT/bench_$w.log" > "$OUT/bench_$w.json"
