@@ -58,7 +58,8 @@ struct SplitW {
 
 struct ConvP {
     SplitW split;
-    float* wfrag = nullptr; // 3x3 stride-1 and 8x8 stride-2 convolutions: the split weights in the fragment order of the window kernels, or null
+    float* wfrag = nullptr; // the split weights in the fragment order of the window kernels, or null
+    int wrows = 0;          // rows of w / wfrag when they are not Cout (conv1 of a down-sampling block carries the shortcut's rows)
     float* w = nullptr;     // [Cout][KH][KW][Cin] (stem: [Cout][Cin][KH][KW])
     float* bias = nullptr;  // folded BatchNorm shift or conv bias (may be null)
     int Cin = 0, Cout = 0, KH = 0, KW = 0, stride = 1, pad = 0;
@@ -385,6 +386,8 @@ int layout_and_pack(danra_handle_s* h, Bump& bp, Bump& bh, std::vector<SplitJob>
                 blk.c1.w = blk.w_both;
                 blk.c1.bias = blk.b_both;
                 if (inpl % 64 == 0) want_split(blk.c1.split, blk.w_both, (size_t)2 * planes, (size_t)9 * inpl);
+                blk.c1.wrows = 2 * planes;
+                blk.c1.wfrag = (inpl % 64 == 0) ? bh.take((size_t)2 * planes * inpl * 9) : nullptr;
                 if (fill) {
                     HIP_TRY(launch_bn_fold(src_of(h, p + ".bn1.weight"), src_of(h, p + ".bn1.bias"),
                                            src_of(h, p + ".bn1.running_mean"), src_of(h, p + ".bn1.running_var"),
@@ -657,6 +660,19 @@ int run_conv(danra_handle_s* h, const ConvP& c, const float* in, float* out, int
         if (slabs) slabs->count = 0;
         return conv_win(h, w, 2.0 * (double)a.M * (double)a.N * (double)a.K,
                         4.0 * ((double)a.N * a.K + (double)a.M * a.N * (res ? 2.0 : 1.0) + (double)B * Hi * Wi * c.Cin), st);
+    }
+    // 3x3 stride-2 convolutions on small maps (conv1 of a down-sampling BasicBlock, with the block's shortcut as further rows)
+    if (c.wfrag && c.KH == 3 && c.KW == 3 && c.stride == 2 && c.pad == 1 && !nmean && !res && !tbias && h->conv_win && h->conv_s2 &&
+        !igemm_fp32_products_forced() && (out2 == nullptr) == (c.wrows == 0 || c.wrows == c.Cout) &&
+        conv_win_supported(B, Hi, Wi, c.Cin, a.N, false, 2)) {
+        ConvWinArgs w;
+        memset(&w, 0, sizeof(w));
+        w.x = in; w.wf = c.wfrag; w.w32 = c.w; w.wscale = c.split.inv_scale; w.bias = c.bias; w.out = out;
+        w.out2 = out2; w.n_split = out2 ? c.Cout : 0; w.stride = 2;
+        w.B = B; w.H = Hi; w.W = Wi; w.Cin = c.Cin; w.Cout = a.N; w.act = a.act; w.tb_stride = h->tb_width;
+        if (slabs) slabs->count = 0;
+        return conv_win(h, w, 2.0 * (double)a.M * (double)a.N * (double)a.K,
+                        4.0 * ((double)a.N * a.K + (double)a.M * a.N + (double)B * Hi * Wi * c.Cin), st);
     }
     // the 8x8 stride-2 convolution: the strided window kernel
     if (c.wfrag && c.KH == 8 && c.KW == 8 && c.stride == 2 && c.pad == 3 && !out2 && !nmean && h->conv_win && h->conv_s2 && !igemm_fp32_products_forced() &&
@@ -1223,7 +1239,7 @@ int danra_pack_weights(danra_handle_t h, void* stream) {
     {   // the weights of the convolutions that go through the window kernels in fragment order, with the scale of their split copy
         auto frag = [&](ConvP& c) -> int {
             if (c.wfrag && !c.split.wh) c.wfrag = nullptr;
-            if (c.wfrag) HIP_TRY(launch_pack_conv_frag(c.w, c.wfrag, c.Cout, c.Cin, 1.0f / c.split.inv_scale, st, c.KH * c.KW));
+            if (c.wfrag) HIP_TRY(launch_pack_conv_frag(c.w, c.wfrag, c.wrows ? c.wrows : c.Cout, c.Cin, 1.0f / c.split.inv_scale, st, c.KH * c.KW));
             return DANRA_OK;
         };
         RC_TRY(frag(h->conv2));
@@ -2014,7 +2030,8 @@ int danra_instance_norm_noalloc(const float* x, float* out, int B, int HW, int C
 // temporary buffer, runs the kernel and waits for it.
 // The per-op entries of the window kernels: scale and pack the weights into a temporary buffer, run, wait.
 static int conv_window_op(int taps, const float* x, const float* w, const float* bias, const float* res, const float* nmean,
-                          const float* nrstd, float* out, int B, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+                          const float* nrstd, float* out, int B, int H, int W, int Cin, int Cout, int relu, hipStream_t st,
+                          int stride = 1, float* out2 = nullptr, int n_split = 0) {
     const size_t n = (size_t)Cout * taps * Cin;
     float* tmp = nullptr;
     if (hipMalloc((void**)&tmp, (n + 64) * sizeof(float)) != hipSuccess) return fail(DANRA_ENOMEM, "temporary weight buffer");
@@ -2032,6 +2049,7 @@ static int conv_window_op(int taps, const float* x, const float* w, const float*
     memset(&a, 0, sizeof(a));
     a.x = x; a.wf = tmp; a.w32 = w; a.wscale = ldexpf(1.0f, -sft); a.bias = bias; a.res = res; a.nmean = nmean; a.nrstd = nrstd; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = relu ? ACT_RELU : ACT_NONE;
+    a.stride = stride; a.out2 = out2; a.n_split = n_split;
     const hipError_t le = taps == 9 ? launch_conv_win(a, st) : launch_conv8s2(a, st);
     const hipError_t se = hipStreamSynchronize(st);
     if (le != hipSuccess || se != hipSuccess) return done(fail(DANRA_EHIP, "window convolution: %s", hipGetErrorString(le != hipSuccess ? le : se)));
@@ -2047,6 +2065,17 @@ int danra_conv3x3(const float* x, const float* w, const float* bias, const float
         return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d%s: not a shape of the window-staged kernel (sides powers of two up to 64 "
                     "wide, Cin %% 64 == 0, Cout %% 32 == 0)", B, H, W, Cin, Cout, nmean ? " with norm on load" : "");
     return conv_window_op(9, x, w, bias, res, nmean, nrstd, out, B, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+int danra_conv3x3s2(const float* x, const float* w, const float* bias, float* out, float* out2, int B, int H, int W, int Cin,
+                    int Cout, int n_split, int relu, void* stream) {
+    if (!x || !w || !out) return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DANRA_EINVAL, "sizes must be positive");
+    if (out2 && (n_split <= 0 || n_split % 32 || n_split >= Cout)) return fail(DANRA_EINVAL, "n_split=%d: a multiple of 32 inside 0..Cout", n_split);
+    if (!conv_win_supported(B, H, W, Cin, Cout, false, 2))
+        return fail(DANRA_EINVAL, "B=%d %dx%d %d->%d: not a shape of the window-staged kernel at stride 2 (sides powers of two, an "
+                    "output map of at most 64 pixels, Cin %% 64 == 0, Cout %% 32 == 0)", B, H, W, Cin, Cout);
+    return conv_window_op(9, x, w, bias, nullptr, nullptr, nullptr, out, B, H, W, Cin, Cout, relu, (hipStream_t)stream, 2, out2, n_split);
 }
 
 int danra_conv8x8s2(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int H, int W, int Cin,

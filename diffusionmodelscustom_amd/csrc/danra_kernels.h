@@ -387,13 +387,16 @@ struct ConvWinArgs {
     const float* nmean;
     const float* nrstd;
     float* out;
-    int B, H, W, Cin, Cout;
+    int B, H, W, Cin, Cout;   // H, W: the input map; Cout: every output column (both outputs with out2)
     int act, tb_stride;
+    int stride;          // 1, or 2 (k_conv_win only: padding 1, output H/2 x W/2; no norm on load)
+    float* out2;         // stride 2 only: columns n_split .. Cout - 1 go here ([rows][Cout - n_split]) with their bias only,
+    int n_split;         // columns 0 .. n_split - 1 to `out` ([rows][n_split]); n_split a multiple of 32; no res / tbias then
     // filled in by launch_conv_win
     int sh_w, sh_hw, lds_img, lds_window, lds_bufs;
 };
 // H, W powers of two (W <= 64), Cin % 64 == 0, Cout % 32 == 0 and a tile shape that fits: otherwise the caller uses launch_igemm
-bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm);
+bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm, int stride = 1);
 hipError_t launch_conv_win(const ConvWinArgs& a, hipStream_t stream);
 // w [Cout][taps][Cin] fp32 -> out (same number of bytes): scale * w split in fp16 halves, in the fragment order of the
 // window kernels (k_conv_win: 9 taps; k_conv8s2: 64)

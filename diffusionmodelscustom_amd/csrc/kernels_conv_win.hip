@@ -40,7 +40,13 @@ __device__ unsigned long long g_win_stamps[8 * 16];
 // whose tiles do little arithmetic per block, a trip to memory per block is what the loop would wait for).  NORM:
 // InstanceNorm of the input applied while the window is staged ((x - mean[b][c]) * rstd[b][c], in-bounds pixels only).
 // PIXM: pixel-major tiles (head of the file).
-template <int NPT, int WCAP, int CBS, bool NORM, bool PIXM, bool PSPLIT>
+// S2: stride 2 (padding 1) on a map of at most 4 TP pixels: the tile's output pixels are whole images, the window their input
+// images as they lie in memory, and a lane's own cell is input pixel (2 oy, 2 ox) of its output pixel - the taps keep their
+// offsets.  (Lanes then read every second cell of a row: two of them share a bank, which these launches, bound by their
+// set-up and their weights, do not notice.)  With p.out2 the output channels from p.n_split on go to a second tensor with
+// their bias only: the 1x1 stride-2 shortcut of a BasicBlock rides along as the centre tap of a 3x3 kernel (the other
+// eight taps of those channels are taken to be zero: they are neither fetched nor multiplied).
+template <int NPT, int WCAP, int CBS, bool NORM, bool PIXM, bool PSPLIT, bool S2 = false>
 __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     constexpr int NW = 8, T = 64 * NW;
     constexpr int TP = 32 * NPT;          // pixels of the tile
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     constexpr int LDO = TN + 4;           // row of a partial tile in LDS (floats)
     constexpr int PS = pixel_bytes(CBS);
     static_assert(!PSPLIT || NPT % 2 == 0, "the pixel tiles are dealt to two wave groups");
+    static_assert(!S2 || (!NORM && !PIXM && !PSPLIT), "stride 2: whole-image tiles, no norm on load");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[3];              // a staged value too large for the split / of normal size / non-zero
 
@@ -76,9 +83,14 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
 
     // ---- tile geometry (all wave-uniform; every extent of a supported map is a power of two).  The window is the run
     // of nwin NHWC pixels from global pixel gstart on; those in [glo, ghi) are staged (the others are never read).
-    const int M = p.B * HW;
-    int b0 = 0, pos = 0, halo = 0, gstart, glo = 0, ghi = M, nwin;
-    if (PIXM) {
+    const int Min = p.B * HW;                    // pixels of the input
+    const int sh_out = p.sh_hw - (S2 ? 2 : 0);   // log2 of the pixels of an output map
+    const int M = S2 ? Min >> 2 : Min;           // pixels (rows) of the output
+    int b0 = 0, pos = 0, halo = 0, gstart, glo = 0, ghi = Min, nwin;
+    if (S2) {                                     // whole output images; the window is their input images
+        b0 = (tile << LTP) >> sh_out;
+        gstart = b0 << p.sh_hw; nwin = 4 * TP;
+    } else if (PIXM) {
         const int tpp = p.B >> LTP;               // tiles per output pixel
         pos = tile / tpp;
         b0 = (tile - pos * tpp) << LTP;
@@ -101,9 +113,13 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     auto tap_id = [&](int ti) -> int {                  // index of the stage's tap ti in the 3x3 kernel
         return PIXM ? ((ti >> 1) - oy + 1) * 3 + (ti & 1) - ox + 1 : ti;
     };
+    // (tile-uniform) these output channels belong to the second output: a 1x1 kernel carried as the centre tap of a 3x3
+    // one, whose other eight taps - zeros - are neither fetched nor multiplied
+    const bool second = S2 && p.out2 != nullptr && n0 >= p.n_split;
     auto wload = [&](f16x8 (&dst)[2], int st, int i) {
         const int j = min(PSPLIT ? i : grp + 2 * i, KSTEPS - 1);   // (past the end: the last one again, never used)
         const int cbl = NTAPS == 4 ? j >> 2 : (j * 57) >> 9, ti = j - cbl * NTAPS;
+        if (S2 && second && ti != 4) return;
         const int cb = min(st * CBS + cbl, NCB - 1);
         const f16x8* src = wsrc + (size_t)((cb * 9 + tap_id(ti)) * 2) * 64;
         dst[0] = src[0];
@@ -181,7 +197,13 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
 #pragma unroll
     for (int t = 0; t < NPTW; ++t) {
         const int q = 32 * (t0 + t) + fr;         // pixel of the tile
-        if (PIXM) {
+        if (S2) {
+            const int il = q >> sh_out, r = q & ((1 << sh_out) - 1), oy = r >> (p.sh_w - 1), ox = r & ((W >> 1) - 1);
+            lbase[t] = ((il << p.sh_hw) + ((2 * oy) << p.sh_w) + 2 * ox) * PS + s * 32 + fh * 16;
+            // input rows 2 oy - 1 .. 2 oy + 1, columns likewise: only the first of each can leave the map
+            const unsigned cols = (ox > 0 ? 1u : 0u) | 6u;
+            tapok[t] = (oy > 0 ? cols : 0u) | cols << 3 | cols << 6;
+        } else if (PIXM) {
             lbase[t] = (int)__umul24(q, IS) + s * 32 + fh * 16;
             tapok[t] = 0xfu;
         } else {
@@ -201,10 +223,11 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     const int oc4 = (tid & 7) * 4;
     const int n = n0 + oc4;
     const float scale = p.wscale;
+    const int ldc = p.out2 ? p.n_split : p.Cout;   // row of the first output
     auto row_of = [&](int q, int& img) -> int {   // row of the output tensor of tile pixel q, or -1
         if (PIXM) { img = b0 + q; return img * HW + pos; }
         const int m = tile * TP + q;
-        img = min(m >> p.sh_hw, p.B - 1);          // (rows past the batch in a ragged last tile: never stored)
+        img = min(m >> sh_out, p.B - 1);           // (rows past the batch in a ragged last tile: never stored)
         return m < M ? m : -1;
     };
     int erow[NROWS], eimg[NROWS];
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
 #pragma unroll
         for (int e = 0; e < NROWS; ++e) {
             const int m = max(erow[e], 0);
-            if (p.res) pre_res[e] = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.Cout + n);
+            if (p.res) pre_res[e] = *reinterpret_cast<const float4*>(p.res + (size_t)m * ldc + n);
             if (p.tbias) pre_tb[e] = *reinterpret_cast<const float4*>(p.tbias + (size_t)eimg[e] * p.tb_stride + n);
         }
     };
@@ -251,6 +274,7 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
             // steps over one another: 1-1.5 us on the kernels with many steps per stage, nothing or a loss on the others)
             if constexpr (CBS >= 4 || NORM) __builtin_amdgcn_sched_barrier(0);
             const int cbl = NTAPS == 4 ? j >> 2 : (j * 57) >> 9, ti = j - cbl * NTAPS;
+            if (S2 && second && ti != 4) continue;
             // where the tap's neighbour lies behind the lane's own pixel (wave-uniform)
             int toff;
             if (PIXM) toff = ti * PS;
@@ -324,10 +348,14 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
 
     auto finish_store = [&](int m, int img, float4 v, float4 rv, float4 tv) {
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (second) {
+            *reinterpret_cast<float4*>(p.out2 + (size_t)m * (p.Cout - p.n_split) + (n - p.n_split)) = v;
+            return;
+        }
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         v.x = act_apply(p.act, v.x); v.y = act_apply(p.act, v.y); v.z = act_apply(p.act, v.z); v.w = act_apply(p.act, v.w);
         v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
-        *reinterpret_cast<float4*>(p.out + (size_t)m * p.Cout + n) = v;
+        *reinterpret_cast<float4*>(p.out + (size_t)m * ldc + n) = v;
     };
     if (!__builtin_amdgcn_readfirstlane(redo ? 1 : 0)) {
 #pragma unroll
@@ -356,12 +384,13 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
         int img;
         const int m = row_of(q, img);
         if (m < 0) continue;
-        const int r = m - img * HW, oy = r >> p.sh_w, ox = r & (W - 1);
+        const int r = m - (img << sh_out), oy = S2 ? r >> (p.sh_w - 1) : r >> p.sh_w, ox = S2 ? r & ((W >> 1) - 1) : r & (W - 1);
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const int K = 9 * Cin;
         for (int kh = 0; kh < 3; ++kh)
             for (int kw = 0; kw < 3; ++kw) {
-                const int iy = oy + kh - 1, ix = ox + kw - 1;
+                if (S2 && second && (kh != 1 || kw != 1)) continue;
+                const int iy = (S2 ? 2 * oy : oy) + kh - 1, ix = (S2 ? 2 * ox : ox) + kw - 1;
                 if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
                 const float* xr = p.x + ((size_t)(img * H + iy) * W + ix) * Cin;
                 const float* wr = p.w32 + (size_t)n * K + (kh * 3 + kw) * Cin;
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
                 }
             }
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), tv = rv;
-        if (p.res) rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.Cout + n);
+        if (p.res) rv = *reinterpret_cast<const float4*>(p.res + (size_t)m * ldc + n);
         if (p.tbias) tv = *reinterpret_cast<const float4*>(p.tbias + (size_t)img * p.tb_stride + n);
         finish_store(m, img, make_float4(a[0], a[1], a[2], a[3]), rv, tv);
     }
@@ -444,6 +473,41 @@ int cap_class(int npt, bool pixm, int nwin) {
 }
 constexpr size_t kLdsBudget = 160 * 1024 - 1024;   // dynamic LDS a workgroup may ask for
 
+// Stride 2: tiles of whole output images (at most 32 NPT pixels each, their input images in the window).
+WinPlan plan_conv_win_s2(int B, int H, int W, int Cin, int Cout) {
+    WinPlan pl;
+    if (log2_pow2(W) < 0 || log2_pow2(H) < 0 || H < 2 || W < 2 || Cin % 64 || Cout % 32 || B <= 0) return pl;
+    const int HWo = H * W / 4;
+    const long M = (long)B * HWo;
+    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1l << 31) || (long)B * H * W >= (1l << 23)) return pl;
+    const int NCB = Cin / 64;
+    for (int npt : {2, 1}) {
+        const int TP = 32 * npt;
+        if (HWo > TP) continue;
+        if (npt == 2 && HWo <= 32 && (M + TP - 1) / TP * (Cout / 32) < 200) continue;   // (rather twice as many workgroups)
+        pl.nwin = 4 * TP;
+        pl.cap = pl.nwin;                       // the instances there are: 256 window pixels for NPT = 2, 128 for NPT = 1
+        for (int cbs : {2, 1}) {
+            if (NCB % cbs || pl.cap * cbs > 256) continue;
+            if (cbs == 1 && NCB > 1) continue;  // (as at stride 1: two wave groups would deal nine taps of one block)
+            const int PSB = pixel_bytes(cbs);
+            const int lds_window = (pl.nwin * PSB + PSB + 255) / 256 * 256;
+            const int stages = NCB / cbs;
+            int bufs = stages > 1 ? 2 : 1;
+            if ((size_t)lds_window * bufs > kLdsBudget) bufs = 1;
+            if ((size_t)lds_window > kLdsBudget) continue;
+            pl.npt = npt; pl.cbs = cbs; pl.bufs = bufs; pl.pixm = false;
+            pl.tiles = (int)((M + TP - 1) / TP);
+            pl.lds_img = 0; pl.lds_window = lds_window;
+            const size_t red = (size_t)4 * TP * (32 + 4) * sizeof(float), win = (size_t)lds_window * bufs;
+            pl.lds = win > red ? win : red;
+            return pl;
+        }
+    }
+    pl.npt = 0;
+    return pl;
+}
+
 // The tile shape for a convolution, or npt = 0 when k_conv_win does not take it.
 WinPlan plan_conv_win(int B, int H, int W, int Cin, int Cout, bool norm) {
     WinPlan pl;
@@ -503,9 +567,9 @@ WinPlan plan_conv_win(int B, int H, int W, int Cin, int Cout, bool norm) {
     return pl;
 }
 
-template <int NPT, int WCAP, int CBS, bool NORM, bool PIXM, bool PSPLIT>
+template <int NPT, int WCAP, int CBS, bool NORM, bool PIXM, bool PSPLIT, bool S2 = false>
 hipError_t launch_one(const ConvWinArgs& a, const WinPlan& pl, hipStream_t stream) {
-    auto kern = k_conv_win<NPT, WCAP, CBS, NORM, PIXM, PSPLIT>;
+    auto kern = k_conv_win<NPT, WCAP, CBS, NORM, PIXM, PSPLIT, S2>;
     if (pl.lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (e != hipSuccess) return e;
@@ -528,19 +592,31 @@ hipError_t launch_cbs(const ConvWinArgs& a, const WinPlan& pl, hipStream_t strea
 
 }  // namespace
 
-bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm) {
-    return plan_conv_win(B, H, W, Cin, Cout, norm).npt != 0;
+bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm, int stride) {
+    if (stride == 2) return !norm && plan_conv_win_s2(B, H, W, Cin, Cout).npt != 0;
+    return stride == 1 && plan_conv_win(B, H, W, Cin, Cout, norm).npt != 0;
 }
 
 hipError_t launch_conv_win(const ConvWinArgs& args, hipStream_t stream) {
     ConvWinArgs a = args;
     const bool norm = a.nmean != nullptr;
-    const WinPlan pl = plan_conv_win(a.B, a.H, a.W, a.Cin, a.Cout, norm);
+    if (a.stride == 0) a.stride = 1;
+    if (a.stride != 1 && a.stride != 2) return hipErrorInvalidValue;
+    if (a.out2 && (a.stride != 2 || a.n_split <= 0 || a.n_split % 32 || a.n_split >= a.Cout || a.res || a.tbias)) return hipErrorInvalidValue;
+    if (!a.out2) a.n_split = 0;
+    if (a.stride == 2 && norm) return hipErrorInvalidValue;
+    const WinPlan pl = a.stride == 2 ? plan_conv_win_s2(a.B, a.H, a.W, a.Cin, a.Cout) : plan_conv_win(a.B, a.H, a.W, a.Cin, a.Cout, norm);
     if (!pl.npt || !a.wf || !a.w32) return hipErrorInvalidValue;
     if (a.tbias && a.tb_stride % 4) return hipErrorInvalidValue;
     a.sh_w = log2_pow2(a.W);
     a.sh_hw = log2_pow2(a.H * a.W);
     a.lds_img = pl.lds_img; a.lds_window = pl.lds_window; a.lds_bufs = pl.bufs;
+    if (a.stride == 2) {
+        if (pl.npt == 2 && pl.cbs == 1) return launch_one<2, 256, 1, false, false, false, true>(a, pl, stream);
+        if (pl.npt == 1 && pl.cbs == 2) return launch_one<1, 128, 2, false, false, false, true>(a, pl, stream);
+        if (pl.npt == 1 && pl.cbs == 1) return launch_one<1, 128, 1, false, false, false, true>(a, pl, stream);
+        return hipErrorInvalidValue;
+    }
 #define DANRA_WIN(NPT_, CAP_, PS_)                                                                                    \
     if (pl.npt == NPT_ && pl.cap == CAP_)                                                                             \
         return norm ? launch_cbs<NPT_, CAP_, true, false, PS_>(a, pl, stream) : launch_cbs<NPT_, CAP_, false, false, PS_>(a, pl, stream);

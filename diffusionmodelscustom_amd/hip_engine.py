@@ -119,6 +119,7 @@ _SIGNATURES = {
     "danra_instance_norm": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_conv3x3": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 6 + [_P]),
     "danra_conv8x8s2": (ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 6 + [_P]),
+    "danra_conv3x3s2": (ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 7 + [_P]),
     "danra_instance_norm_noalloc": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_edm_perturb": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_uint64,
                                                                                               ctypes.c_uint64, _P]),

@@ -381,6 +381,16 @@ int danra_decoder_block(danra_handle_t h, int block, const float* fmap_nhwc, con
  * Cout % 32 == 0.  Allocates a temporary copy of the weights and waits for the stream. */
 int danra_conv3x3(const float* x_nhwc, const float* w, const float* bias, const float* res_nhwc, const float* nmean,
                   const float* nrstd, float* out_nhwc, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* One 3x3 stride-2 padding-1 convolution as the first convolution of a down-sampling BasicBlock applies it (torchvision
+ * resnet.BasicBlock.conv1 under modules:285-303), through the window-staged kernel, for unit tests: NHWC x [B][H][W][Cin]
+ * -> [B][H/2][W/2][.], w [Cout][3][3][Cin], optional bias and ReLU.  With out2 the output channels from n_split on go to
+ * out2 ([B][H/2][W/2][Cout - n_split]) with their bias and no ReLU, the first n_split to out: how the library runs the
+ * block's 1x1 stride-2 shortcut in the same launch (its weights as the centre tap of a 3x3 kernel; the other eight taps of
+ * those channels are taken to be zero and are not read).
+ * H, W powers of two with H*W/4 <= 64, Cin % 64 == 0, Cout % 32 == 0.  Allocates a temporary copy of the weights and waits
+ * for the stream. */
+int danra_conv3x3s2(const float* x_nhwc, const float* w, const float* bias, float* out_nhwc, float* out2_nhwc, int B, int H,
+                    int W, int Cin, int Cout, int n_split, int relu, void* stream);
 /* One 8x8 stride-2 padding-3 convolution as Encoder.conv2 applies it (modules:186-191, 269-273; bn1 folded into w and
  * bias by the caller), through the strided window kernel, for unit tests: NHWC x [B][H][W][Cin] -> [B][H/2][W/2][Cout],
  * w [Cout][8][8][Cin], optional bias, residual (NHWC, added before the optional ReLU).  H, W powers of two >= 16,

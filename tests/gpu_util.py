@@ -136,3 +136,18 @@ def conv8x8s2(lib, x, w, bias=None, res=None, relu=False):
     _check(lib, lib.danra_conv8x8s2(_ptr(xin), _ptr(wp), _ptr(bias), _ptr(rin), _ptr(out), B, H, W, Cin, Cout, int(relu),
                                     _stream()), "danra_conv8x8s2")
     return to_nchw(lib, out)
+
+
+def conv3x3s2(lib, x, w, bias=None, n_split=0, relu=False):
+    """danra_conv3x3s2 on NCHW tensors: x [B, Cin, H, W], w [Cout, Cin, 3, 3] -> [B, Cout, H/2, W/2], or with n_split the pair
+    ([B, n_split, ..] with the ReLU, [B, Cout - n_split, ..] without)."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xin = to_nhwc(lib, x)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    first = n_split if n_split else Cout
+    out = torch.empty((B, H // 2, W // 2, first), device=x.device, dtype=torch.float32)
+    out2 = torch.empty((B, H // 2, W // 2, Cout - first), device=x.device, dtype=torch.float32) if n_split else None
+    _check(lib, lib.danra_conv3x3s2(_ptr(xin), _ptr(wp), _ptr(bias), _ptr(out), _ptr(out2), B, H, W, Cin, Cout, n_split, int(relu),
+                                    _stream()), "danra_conv3x3s2")
+    return to_nchw(lib, out) if not n_split else (to_nchw(lib, out), to_nchw(lib, out2))

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from diffusionmodelscustom_amd import hip_engine
-from gpu_util import conv3x3
+from gpu_util import conv3x3, conv3x3s2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -158,3 +158,96 @@ def test_nan_reaches_the_outputs_whose_window_holds_it_and_no_others():
     assert torch.isnan(got.permute(0, 2, 3, 1)[hit]).all()
     keep = ~hit[:, None].expand_as(got)
     assert torch.equal(got[keep], clean[keep])
+
+
+# ---- stride 2 (the first convolution of a down-sampling BasicBlock, with the block's 1x1 stride-2 shortcut as further
+# output channels: torchvision resnet.BasicBlock under modules_DANRA_conditional.py:285-303)
+S2_SHAPES = [
+    (64, 16, 16, 64, 256),    # one output image per 64-pixel tile, one channel block
+    (64, 8, 8, 128, 512),     # two images per 32-pixel tile, two channel blocks in one stage
+    (64, 4, 4, 256, 1024),    # eight images per tile, two stages, two window buffers
+    (3, 8, 8, 128, 64),       # ragged: the last tile holds one image
+    (5, 4, 4, 256, 96),
+    (1, 16, 16, 64, 32),
+    (6, 2, 2, 128, 64),       # a one-pixel output map
+    (2, 8, 16, 64, 64),       # a rectangular map
+]
+
+
+def reference_s2(x, w, bias, n_split, relu):
+    y = torch.nn.functional.conv2d(x.double(), w.double(), None if bias is None else bias.double(), stride=2, padding=1)
+    if not n_split:
+        return torch.relu(y) if relu else y
+    first = torch.relu(y[:, :n_split]) if relu else y[:, :n_split]
+    return first, y[:, n_split:]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", S2_SHAPES)
+def test_stride_two_against_float64(B, H, W, Cin, Cout):
+    lib = hip_engine.load_library()
+    g = torch.Generator().manual_seed(B * 1000 + H * 100 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    got = conv3x3s2(lib, x.to(DEV), w.to(DEV), bias.to(DEV), relu=True).cpu().double()
+    want = reference_s2(x, w, bias, 0, True)
+    assert got.shape == want.shape
+    assert rel(got, want) < TOL_OP
+    plain = conv3x3s2(lib, x.to(DEV), w.to(DEV)).cpu().double()
+    assert rel(plain, reference_s2(x, w, None, 0, False)) < TOL_OP
+    assert torch.equal(conv3x3s2(lib, x.to(DEV), w.to(DEV), bias.to(DEV), relu=True).cpu().double(), got)
+    if Cout % 64 == 0:
+        # the second half of the channels as a block's shortcut: zero but for the centre tap, no ReLU, its own tensor
+        n_split = Cout // 2
+        w2 = w.clone()
+        centre = w2[n_split:, :, 1, 1].clone()
+        w2[n_split:] = 0.0
+        w2[n_split:, :, 1, 1] = centre
+        a, b2 = conv3x3s2(lib, x.to(DEV), w2.to(DEV), bias.to(DEV), n_split=n_split, relu=True)
+        wa, wb = reference_s2(x, w2, bias, n_split, True)
+        assert rel(a.cpu().double(), wa) < TOL_OP and rel(b2.cpu().double(), wb) < TOL_OP
+        one_by_one = torch.nn.functional.conv2d(x.double(), centre.double()[:, :, None, None], bias[n_split:].double(), stride=2)
+        assert rel(b2.cpu().double(), one_by_one) < TOL_OP
+
+
+@pytest.mark.parametrize("case", ["huge_value", "tiny", "zeros", "band_gaussian_3e-3", "nan"])
+def test_stride_two_value_ranges(case):
+    lib = hip_engine.load_library()
+    B, H, W, Cin, Cout = 6, 8, 8, 128, 64
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    if case == "huge_value":
+        x[0, 5, 4, 7] = 3.0e6
+    elif case == "tiny":
+        x *= 1.0e-6
+    elif case == "zeros":
+        x[0] = 0.0
+        x[1] = 0.0
+    elif case == "band_gaussian_3e-3":
+        x *= 3.0e-3
+    elif case == "nan":
+        x[2, 9, 5, 3] = float("nan")     # read by the outputs (2, 2) and (3, 2) x (1, 1) and (2, 1): rows 4..6 -> oy 2, 3; columns 2..4 -> ox 1, 2
+    got = conv3x3s2(lib, x.to(DEV), w.to(DEV)).cpu().double()
+    if case == "nan":
+        hit = torch.zeros(B, H // 2, W // 2, dtype=torch.bool)
+        hit[2, 2:4, 1:3] = True
+        assert torch.isnan(got.permute(0, 2, 3, 1)[hit]).all()
+        x[2, 9, 5, 3] = 0.0
+        want = reference_s2(x, w, None, 0, False)
+        keep = ~hit[:, None].expand_as(got)
+        assert float((got[keep] - want[keep]).abs().max()) <= TOL_OP * float(want.abs().max())
+        return
+    want = reference_s2(x, w, None, 0, False)
+    assert torch.isfinite(got).all()
+    for b in range(B):
+        scale = max(float(want[b].abs().max()), 1e-30)
+        assert float((got[b] - want[b]).abs().max()) <= TOL_OP * scale, (case, b)
+
+
+def test_stride_two_refuses_what_it_does_not_take():
+    lib = hip_engine.load_library()
+    with pytest.raises(RuntimeError, match="not a shape of the window-staged kernel at stride 2"):
+        conv3x3s2(lib, torch.zeros(1, 64, 32, 32, device=DEV), torch.ones(32, 64, 3, 3, device=DEV))     # a 256-pixel output map
+    with pytest.raises(RuntimeError, match="n_split"):
+        conv3x3s2(lib, torch.zeros(1, 64, 8, 8, device=DEV), torch.ones(64, 64, 3, 3, device=DEV), n_split=48)
