@@ -393,7 +393,7 @@ struct ConvWinArgs {
     float* out2;         // stride 2 only: columns n_split .. Cout - 1 go here ([rows][Cout - n_split]) with their bias only,
     int n_split;         // columns 0 .. n_split - 1 to `out` ([rows][n_split]); n_split a multiple of 32; no res / tbias then
     // filled in by launch_conv_win
-    int sh_w, sh_hw, lds_img, lds_window, lds_bufs;
+    int sh_w, sh_hw, lds_img, lds_window, lds_bufs, swap_grid;
 };
 // H, W powers of two (W <= 64), Cin % 64 == 0, Cout % 32 == 0 and a tile shape that fits: otherwise the caller uses launch_igemm
 bool conv_win_supported(int B, int H, int W, int Cin, int Cout, bool norm, int stride = 1);

@@ -73,8 +73,11 @@ __global__ __launch_bounds__(512) void k_conv_win(const ConvWinArgs p) {
     // (Numbering the workgroups so that those of one XCD share a channel tile - and with it the weights in that XCD's L2 -
     // was measured and dropped: the 32 CUs of an XCD then ask the same L2 lines at the same time, 5-10 % slower on the
     // 16x16 ... 4x4 maps, 5 % faster on the 2x2 ones, 1.8 % slower over a whole evaluation.)
-    const int tile = blockIdx.x;
-    const int n0 = blockIdx.y * TN;
+    // (... except where a launch has few pixel tiles and many channel tiles - the 2x2 maps: there the channel tile is the
+    // fast index, each XCD's workgroups share an eighth of the channel tiles, and the weights - 9 MB against 0.5 MB of
+    // input - cross the fabric once instead of eight times: launch_one swaps the roles of the grid's axes.)
+    const int tile = p.swap_grid ? blockIdx.y : blockIdx.x;
+    const int n0 = (p.swap_grid ? blockIdx.x : blockIdx.y) * TN;
     const int H = p.H, W = p.W, Cin = p.Cin, HW = H * W;
     const int NCB = Cin >> 6;
     const int NST = NCB / CBS;            // stages
@@ -577,7 +580,10 @@ hipError_t launch_one(const ConvWinArgs& a, const WinPlan& pl, hipStream_t strea
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (e != hipSuccess) return e;
     }
-    DANRA_LAUNCH_KERNEL(kern, dim3(pl.tiles, a.Cout / 32), dim3(512), pl.lds, stream, a);
+    ConvWinArgs b = a;
+    b.swap_grid = (PIXM || (S2 && pl.tiles <= 8)) ? 1 : 0;
+    const dim3 grid = b.swap_grid ? dim3(a.Cout / 32, pl.tiles) : dim3(pl.tiles, a.Cout / 32);
+    DANRA_LAUNCH_KERNEL(kern, grid, dim3(512), pl.lds, stream, b);
     return hipGetLastError();
 }
 
