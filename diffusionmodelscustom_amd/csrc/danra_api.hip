@@ -1574,6 +1574,46 @@ int danra_conv3x3_c1_train_wgrad(const float* x, const float* dy, float* dw, int
     return DANRA_OK;
 }
 
+int danra_conv8x8s2_train_supported(int B, int Cin, int Cout, int H, int W) {
+    return conv8s2_train_supported(B, Cin, Cout, H, W) ? 1 : 0;
+}
+
+int danra_conv8x8s2_train_dgrad_supported(int B, int Cin, int Cout, int H, int W) {
+    return conv8s2_train_dgrad_supported(B, Cin, Cout, H, W) ? 1 : 0;
+}
+
+size_t danra_conv8x8s2_train_workspace(int B, int Cin, int Cout, int H, int W) {
+    return conv8s2_train_supported(B, Cin, Cout, H, W) ? conv8s2_train_workspace_floats(B, Cin, Cout, H, W) * sizeof(float) : 0;
+}
+
+static int conv8_train_check(const void* a, const void* b, const void* c, int B, int Cin, int Cout, int H, int W, bool dgrad) {
+    if (!a || !b || !c) return fail(DANRA_EINVAL, "null argument");
+    if (!(dgrad ? conv8s2_train_dgrad_supported(B, Cin, Cout, H, W) : conv8s2_train_supported(B, Cin, Cout, H, W)))
+        return fail(DANRA_EINVAL, "B=%d Cin=%d Cout=%d H=%d W=%d: not a shape the 8x8 stride-2 training kernels take "
+                    "(danra_conv8x8s2_train_%ssupported)", B, Cin, Cout, H, W, dgrad ? "dgrad_" : "");
+    return DANRA_OK;
+}
+
+int danra_conv8x8s2_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, void* stream) {
+    RC_TRY(conv8_train_check(x, w, y, B, Cin, Cout, H, W, false));
+    HIP_TRY(launch_conv8s2_train_fwd(x, w, y, B, Cin, Cout, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv8x8s2_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W, void* stream) {
+    RC_TRY(conv8_train_check(dy, w, dx, B, Cin, Cout, H, W, true));
+    HIP_TRY(launch_conv8s2_train_dgrad(dy, w, dx, B, Cin, Cout, H, W, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv8x8s2_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                void* workspace, void* stream) {
+    RC_TRY(conv8_train_check(x, dy, dw, B, Cin, Cout, H, W, false));
+    if (!workspace) return fail(DANRA_EINVAL, "null workspace");
+    HIP_TRY(launch_conv8s2_train_wgrad(x, dy, dw, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_ln_tokens_supported(int B, int C, int L) { return ln_tokens_supported(B, C, L) ? 1 : 0; }
 
 size_t danra_ln_tokens_workspace(int B, int C, int L) { return ln_tokens_workspace_floats(B, C, L) * sizeof(float); }

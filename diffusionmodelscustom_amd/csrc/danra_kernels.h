@@ -127,6 +127,17 @@ hipError_t launch_conv_c1_train_fwd(const float* x, const float* w, float* y, in
 hipError_t launch_conv_c1_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, hipStream_t stream);
 hipError_t launch_conv_c1_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, float* workspace,
                                       hipStream_t stream);
+// The 8x8 stride-2 padding-3 convolutions of the stem in a training step, NCHW fp32 (kernels_conv8_train.hip): x, dx
+// [B][Cin][H][W]; w, dw [Cout][Cin][8][8]; y, dy [B][Cout][H/2][W/2]; workspace: conv8s2_train_workspace_floats floats.
+bool conv8s2_train_supported(int B, int Cin, int Cout, int H, int W);
+bool conv8s2_train_dgrad_supported(int B, int Cin, int Cout, int H, int W);
+size_t conv8s2_train_workspace_floats(int B, int Cin, int Cout, int H, int W);
+hipError_t launch_conv8s2_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W,
+                                    hipStream_t stream);
+hipError_t launch_conv8s2_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W,
+                                      hipStream_t stream);
+hipError_t launch_conv8s2_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                      float* workspace, hipStream_t stream);
 // softmax(q k^T / sqrt(hd)) v of the short-sequence attention blocks for training (kernels_attn_small_train.hip): q, k, v,
 // dq, dk, dv [B*heads][L][hd]; out, dout [B][L][heads*hd].
 bool attention_small_train_supported(int B, int heads, int L, int hd);

@@ -64,6 +64,12 @@ _SIGNATURES = {
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_attention_core_presplit_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_fp32_products": (ctypes.c_int, [ctypes.c_int]),
+    "danra_conv8x8s2_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "danra_conv8x8s2_train_dgrad_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "danra_conv8x8s2_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "danra_conv8x8s2_train_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P]),
+    "danra_conv8x8s2_train_dgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P]),
+    "danra_conv8x8s2_train_wgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_conv3x3_c1_train_supported": (ctypes.c_int, [ctypes.c_int] * 4),
     "danra_conv3x3_c1_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "danra_conv3x3_c1_train_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
@@ -676,6 +682,49 @@ class _Conv3x3C1Train(torch.autograd.Function):
         return dx, dw
 
 
+class _Conv8x8S2Train(torch.autograd.Function):
+    """torch.nn.functional.conv2d(x, weight, None, stride=2, padding=3) for an 8x8 kernel (the two stem convolutions of the
+    encoder) on a contiguous NCHW fp32 CUDA tensor: forward, data gradient and weight gradient in libdanra_hip.so
+    (danra_conv8x8s2_train_fwd / _dgrad / _wgrad), tensors and weight used where they lie."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight):
+        lib = load_library()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B, Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_conv8x8s2_train_fwd(_ptr(x), _ptr(weight), _ptr(y), B, Cin, Cout, H, W, _stream()),
+                   "danra_conv8x8s2_train_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = _f32(dy, "dy")
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(lib, lib.danra_conv8x8s2_train_dgrad(_ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W, _stream()),
+                       "danra_conv8x8s2_train_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                ws = torch.empty(max(lib.danra_conv8x8s2_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=x.device,
+                                 dtype=torch.float32)
+                _check(lib, lib.danra_conv8x8s2_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws), _stream()),
+                       "danra_conv8x8s2_train_wgrad")
+        return dx, dw
+
+
 class _LNTokens(torch.autograd.Function):
     """x [B, C, H, W] -> LayerNorm_C(x.view(B, C, H*W).transpose(1, 2)) as [B, H*W, C]: the entry of an attention block,
     forward and backward as one kernel each in libdanra_hip.so (danra_ln_tokens_fwd / _bwd): no transposed copy of the map."""
@@ -860,6 +909,17 @@ def conv2d(conv, x):
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)[:, :, ::2, ::2]
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    # 8x8, stride 2, padding 3, no bias: the two stem convolutions (an input that asks for a gradient needs the data-gradient
+    # kernel, which exists for 32-channel multiples only)
+    if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
+            and type(conv) is torch.nn.Conv2d and conv.kernel_size == (8, 8) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.bias is None
+            and _native_dtype(x) and conv.weight.dtype == torch.float32 and (x.requires_grad or conv.weight.requires_grad)):
+        B, Cin, H, W = x.shape
+        lib = load_library()
+        if (lib.danra_conv8x8s2_train_dgrad_supported if x.requires_grad else lib.danra_conv8x8s2_train_supported)(
+                B, Cin, conv.out_channels, H, W):
+            return _Conv8x8S2Train.apply(x, conv.weight)
     if (type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and _pointwise_ok(x, conv.weight)):
         B, Cin, H, W = x.shape

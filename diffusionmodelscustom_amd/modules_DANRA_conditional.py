@@ -20,7 +20,7 @@ from typing import Iterable, Optional
 import torch
 import torch.nn as nn
 
-from .resnet import BasicBlock, ResNet, norm_relu
+from .resnet import BasicBlock, ResNet, conv2d, norm_relu
 
 __all__ = ["SinusoidalEmbedding", "ImageSelfAttention", "Encoder", "DecoderBlock", "Decoder", "DiffusionNet",
            "ResNet", "BasicBlock", "torch", "nn", "Optional", "Iterable"]
@@ -173,8 +173,8 @@ class Encoder(ResNet):
             fmap = fmap + self.time_projection_layers[level](emb)[:, :, None, None]
             return self.attention_layers[level](fmap)
 
-        fmap1 = stage(0, self.conv1(x))
-        h = norm_relu(self.bn1, self.relu, self.conv2(fmap1))
+        fmap1 = stage(0, conv2d(self.conv1, x))   # (the training step's stem convolutions run in the native library)
+        h = norm_relu(self.bn1, self.relu, conv2d(self.conv2, fmap1))
         fmap2 = stage(1, self.layer1(h))
         fmap3 = stage(2, self.layer2(fmap2))
         fmap4 = stage(3, self.layer3(fmap3))

@@ -12,8 +12,8 @@ __all__ = ["BasicBlock", "ResNet", "norm_relu", "conv2d"]
 
 
 def conv2d(conv, x):
-    """``conv(x)``; on a CUDA tensor with gradients enabled a 3x3 stride-1 convolution runs forward and backward in
-    ``libdanra_hip.so`` where it has the shape (hip_engine.conv2d)."""
+    """``conv(x)``; on a CUDA tensor with gradients enabled the convolutions of the network (3x3, 8x8 stride 2, 1x1 stride
+    2) run forward and backward in ``libdanra_hip.so`` where it has the shape (hip_engine.conv2d)."""
     if x.is_cuda:
         from . import hip_engine
         return hip_engine.conv2d(conv, x)

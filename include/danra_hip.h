@@ -272,6 +272,22 @@ int danra_conv3x3_c1_train_fwd(const float* x_dev, const float* w_dev, float* y_
 int danra_conv3x3_c1_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int H, int W, void* stream);
 int danra_conv3x3_c1_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int H, int W,
                                  void* workspace, void* stream);
+/* The two stem convolutions of the encoder in a training step: 8x8, stride 2, padding 3, no bias
+ * (modules_DANRA_conditional.py:186-191: conv1 on the 1-4 input planes, conv2 64 -> 64), on contiguous NCHW fp32 tensors with
+ * the [Cout][Cin][8][8] weight as torch holds it: x, dx [B][Cin][H][W]; y, dy [B][Cout][H/2][W/2].  Shapes
+ * (danra_conv8x8s2_train_supported): H, W even, W/2 a power of two in 8..64, H/2 a multiple of 64 / (W/2), Cout a multiple of
+ * 64, Cin a multiple of 32 or at most 4; the data gradient exists for Cin a multiple of 32 only (_dgrad_supported: the
+ * gradient with respect to the network's input planes is never asked for).  workspace (weight gradient only):
+ * danra_conv8x8s2_train_workspace(...) bytes of device memory; sums over workgroups in a fixed order (bit-reproducible). */
+int danra_conv8x8s2_train_supported(int B, int Cin, int Cout, int H, int W);
+int danra_conv8x8s2_train_dgrad_supported(int B, int Cin, int Cout, int H, int W);
+size_t danra_conv8x8s2_train_workspace(int B, int Cin, int Cout, int H, int W);
+int danra_conv8x8s2_train_fwd(const float* x_dev, const float* w_dev, float* y_dev, int B, int Cin, int Cout, int H, int W,
+                              void* stream);
+int danra_conv8x8s2_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int Cout, int H, int W,
+                                void* stream);
+int danra_conv8x8s2_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
+                                void* workspace_dev, void* stream);
 /* Entry and exit of ImageSelfAttention.forward (modules_DANRA_conditional.py:93-110) in the training step, on the NCHW map the
  * block receives and returns (L = H*W tokens of C channels):
  *   danra_ln_tokens_fwd : normed[b][l][c] = LayerNorm_C(x[b][.][l])[c] * gamma[c] + beta[c]   (x.view(B, C, L).swapaxes(1, 2)

@@ -667,6 +667,8 @@ EXPECTED_NATIVE_CALLS = {"danra_conv3x3_c1_train_fwd": 1, "danra_conv3x3_c1_trai
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
                          "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 20, "danra_conv3x3_train_dgrad": 20,
                          "danra_conv3x3_train_wgrad": 20,
+                         # the two 8x8 stride-2 stem convolutions (conv1's input planes ask for no gradient)
+                         "danra_conv8x8s2_train_fwd": 2, "danra_conv8x8s2_train_dgrad": 1, "danra_conv8x8s2_train_wgrad": 2,
                          # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
                          "danra_pointwise_train_fwd": 8, "danra_pointwise_train_dgrad": 8, "danra_pointwise_train_wgrad": 8,
                          # entry and exit of the nine attention blocks

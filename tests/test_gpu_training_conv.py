@@ -271,3 +271,85 @@ def test_one_output_channel_convolution_matches_float64(B, Cin, H, W):
     close(xr.grad.cpu(), xd.grad, "module data gradient")
     close(conv.weight.grad.cpu(), wd.grad, "module weight gradient")
     close(conv.bias.grad.cpu(), dy.double().cpu().sum().view(1), "module bias gradient")
+
+
+# the stem convolutions of the 64x64 and 128x128 networks at every count of input planes (x alone .. x + lsm + topo + cond),
+# conv2 at both sizes, 32x32 and 16x16 inputs (eight-row tiles), a rectangular map, more channels than the network has,
+# and a batch large enough for 256 slabs of the weight gradient
+STEM_SHAPES = [
+    (3, 4, 64, 64, 64), (2, 3, 64, 64, 64), (2, 2, 64, 64, 64), (2, 1, 64, 64, 64), (2, 64, 64, 32, 32),
+    (1, 4, 64, 128, 128), (2, 64, 64, 64, 64), (1, 1, 64, 32, 32), (2, 32, 64, 16, 16), (3, 64, 128, 32, 64),
+    (32, 64, 64, 32, 32), (32, 4, 64, 64, 64), (1, 96, 192, 16, 32),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", STEM_SHAPES)
+def test_stem_convolution_kernels_match_float64(B, Cin, Cout, H, W):
+    """nn.Conv2d(Cin, Cout, 8, stride 2, padding 3, bias=False) - the encoder's conv1 and conv2
+    (modules_DANRA_conditional.py:186-191) - in the library: forward, weight gradient and (32-channel multiples) data
+    gradient against float64 conv2d on the CPU, bit-identical between calls; then through the module hook."""
+    lib = hip_engine.load_library()
+    assert lib.danra_conv8x8s2_train_supported(B, Cin, Cout, H, W)
+    has_dgrad = bool(lib.danra_conv8x8s2_train_dgrad_supported(B, Cin, Cout, H, W))
+    assert has_dgrad == (Cin % 32 == 0)
+    g = torch.Generator().manual_seed(B * 1000 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 8, 8, generator=g) / (8.0 * Cin ** 0.5)).to(DEV)
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g).to(DEV)
+    ws = torch.empty(max(lib.danra_conv8x8s2_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=DEV)
+
+    def run():
+        y, dx, dw = torch.empty_like(dy), torch.full_like(x, float("nan")), torch.empty_like(w)
+        _check(lib, lib.danra_conv8x8s2_train_fwd(_ptr(x), _ptr(w), _ptr(y), B, Cin, Cout, H, W, _stream()), "fwd")
+        if has_dgrad:
+            _check(lib, lib.danra_conv8x8s2_train_dgrad(_ptr(dy), _ptr(w), _ptr(dx), B, Cin, Cout, H, W, _stream()), "dgrad")
+        _check(lib, lib.danra_conv8x8s2_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws), _stream()), "wgrad")
+        torch.cuda.synchronize()
+        return y, dx, dw
+    y, dx, dw = run()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    want = torch.nn.functional.conv2d(xd, wd, None, 2, 3)
+    want.backward(dy.double().cpu())
+    close(y.cpu(), want.detach(), "forward")
+    if has_dgrad:
+        close(dx.cpu(), xd.grad, "data gradient")
+    close(dw.cpu(), wd.grad, "weight gradient")
+    for a, b, what in zip((y, dx, dw), run(), ("forward", "data gradient", "weight gradient")):
+        assert torch.equal(a, b, ) or (what == "data gradient" and not has_dgrad), f"{what}: two calls differ"
+    # the module hook: the input asks for a gradient only where the data-gradient kernel exists
+    conv = torch.nn.Conv2d(Cin, Cout, 8, 2, 3, bias=False).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xr = x.clone().requires_grad_(has_dgrad)
+    calls = []
+    real = hip_engine._Conv8x8S2Train.apply
+    try:
+        hip_engine._Conv8x8S2Train.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        out = hip_engine.conv2d(conv, xr)
+    finally:
+        hip_engine._Conv8x8S2Train.apply = real
+    assert calls, "the native kernels did not run"
+    out.backward(dy)
+    assert torch.equal(out.detach(), y) and torch.equal(conv.weight.grad, dw)
+    if has_dgrad:
+        assert torch.equal(xr.grad, dx)
+
+
+def test_stem_convolution_refusals():
+    lib = hip_engine.load_library()
+    for B, Cin, Cout, H, W in [(2, 5, 64, 64, 64), (2, 64, 32, 32, 32), (2, 64, 64, 31, 32), (2, 64, 64, 32, 24),
+                               (2, 64, 64, 8, 8), (2, 64, 64, 256, 256), (0, 64, 64, 32, 32), (2, 64, 64, 20, 32)]:
+        assert not lib.danra_conv8x8s2_train_supported(B, Cin, Cout, H, W), (B, Cin, Cout, H, W)
+        assert lib.danra_conv8x8s2_train_workspace(B, Cin, Cout, H, W) == 0
+    assert lib.danra_conv8x8s2_train_supported(2, 4, 64, 64, 64) and not lib.danra_conv8x8s2_train_dgrad_supported(2, 4, 64, 64, 64)
+    x = torch.zeros(2, 4, 64, 64, device=DEV)
+    w = torch.zeros(64, 4, 8, 8, device=DEV)
+    dy = torch.zeros(2, 64, 32, 32, device=DEV)
+    rc = lib.danra_conv8x8s2_train_dgrad(_ptr(dy), _ptr(w), _ptr(x), 2, 4, 64, 64, 64, _stream())
+    assert rc != 0 and b"danra_conv8x8s2_train_dgrad_supported" in lib.danra_last_error()
+    # an input that asks for a gradient where no data-gradient kernel exists: the module itself
+    conv = torch.nn.Conv2d(4, 64, 8, 2, 3, bias=False).to(DEV)
+    xr = torch.randn(2, 4, 64, 64, device=DEV, requires_grad=True)
+    out = hip_engine.conv2d(conv, xr)
+    out.sum().backward()
+    assert xr.grad is not None and torch.isfinite(xr.grad).all()
