@@ -1406,14 +1406,14 @@ int danra_attention_small_bwd(const float* q, const float* k, const float* v, co
 
 int danra_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                               float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
-                              float momentum, int relu, void* stream) {
+                              float momentum, int relu, long long* num_batches_tracked, void* stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");
     if ((running_mean == nullptr) != (running_var == nullptr)) return fail(DANRA_EINVAL, "running_mean and running_var go together");
     if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * HW < 2 || (long long)B * C * HW >= (1LL << 31))
         return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, at least two values per channel, "
                     "fewer than 2^31 elements", B, C, HW);
     HIP_TRY(launch_bn_train_fwd(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, B, C, HW, eps, momentum,
-                                relu ? 1 : 0, (hipStream_t)stream));
+                                relu ? 1 : 0, (hipStream_t)stream, nullptr, num_batches_tracked));
     return DANRA_OK;
 }
 
@@ -1431,14 +1431,14 @@ int danra_batchnorm_train_bwd(const float* x, const float* dy, const float* y, c
 
 int danra_batchnorm_train_add_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                        float* save_mean, float* save_rstd, float* running_mean, float* running_var, int B, int C,
-                                       int HW, float eps, float momentum, void* stream) {
+                                       int HW, float eps, float momentum, long long* num_batches_tracked, void* stream) {
     if (!x || !res || !gamma || !beta || !y || !save_mean || !save_rstd) return fail(DANRA_EINVAL, "null argument");
     if ((running_mean == nullptr) != (running_var == nullptr)) return fail(DANRA_EINVAL, "running_mean and running_var go together");
     if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * HW < 2 || (long long)B * C * HW >= (1LL << 31))
         return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, at least two values per channel, "
                     "fewer than 2^31 elements", B, C, HW);
     HIP_TRY(launch_bn_train_fwd(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, B, C, HW, eps, momentum, 1,
-                                (hipStream_t)stream, res));
+                                (hipStream_t)stream, res, num_batches_tracked));
     return DANRA_OK;
 }
 

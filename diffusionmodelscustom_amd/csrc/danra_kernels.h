@@ -324,10 +324,12 @@ hipError_t launch_edm_finish(float* images, const float* inpaint, const unsigned
 
 // ---------------------------------------------------------------- training step
 // BatchNorm2d in train mode on NCHW fp32 (HW a multiple of 4): batch statistics, optional fused ReLU; save_mean / save_rstd
-// [C] feed the backward pass; running_mean / running_var (may be null) are updated with `momentum` (unbiased variance).
+// [C] feed the backward pass; running_mean / running_var (may be null) are updated with `momentum` (unbiased variance);
+// *batches (may be null; the module's int64 num_batches_tracked) is incremented by one.
 hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                                float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
-                               float momentum, int relu, hipStream_t stream, const float* res = nullptr);
+                               float momentum, int relu, hipStream_t stream, const float* res = nullptr,
+                               long long* batches = nullptr);
 // y is the forward's output (read only with relu, for the mask)
 hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
                                const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,

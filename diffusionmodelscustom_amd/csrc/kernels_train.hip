@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float* __restrict__ 
                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                                       int B, int C, int HW, float eps, float momentum, int relu,
-                                                      const float* __restrict__ res) {
+                                                      const float* __restrict__ res, long long* __restrict__ batches) {
     __shared__ float red[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int hw4 = HW / 4;            // HW is a multiple of 4 (checked by the launcher)
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_bn_train_fwd(const float* __restrict__ 
             running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (var * (n / fmaxf(n - 1.0f, 1.0f)));
         }
+        if (batches && c == 0) *batches += 1;   // nn.BatchNorm2d.num_batches_tracked (one writer per launch)
     }
 }
 
@@ -215,10 +216,10 @@ hipError_t launch_in_train_bwd(const float* x, const float* dy, const float* sav
 
 hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                                float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
-                               float momentum, int relu, hipStream_t stream, const float* res) {
+                               float momentum, int relu, hipStream_t stream, const float* res, long long* batches) {
     if (HW % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bn_train_fwd, dim3(C), dim3(256), 0, stream, x, gamma, beta, y, save_mean, save_rstd, running_mean,
-                       running_var, B, C, HW, eps, momentum, relu, res);
+                       running_var, B, C, HW, eps, momentum, relu, res, batches);
     return hipGetLastError();
 }
 

@@ -81,10 +81,10 @@ _SIGNATURES = {
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
     "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, _P]),
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, _P, _P]),
     "danra_batchnorm_train_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, _P]),
-    "danra_batchnorm_train_add_relu_fwd": (ctypes.c_int, [_P] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _P]),
+    "danra_batchnorm_train_add_relu_fwd": (ctypes.c_int, [_P] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _P, _P]),
     "danra_batchnorm_train_add_relu_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int] * 3 + [_P]),
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
@@ -455,11 +455,12 @@ def differentiable_attention_supported(mha, tokens):
 
 class _BatchNormTrain(torch.autograd.Function):
     """nn.BatchNorm2d in train mode (+ optional ReLU) on a contiguous NCHW fp32 CUDA tensor, forward and backward in
-    libdanra_hip.so (danra_batchnorm_train_fwd / _bwd).  The running statistics are updated in place by the kernel."""
+    libdanra_hip.so (danra_batchnorm_train_fwd / _bwd).  The running statistics and the int64 counter `batches`
+    (num_batches_tracked) are updated in place by the kernel."""
 
     @staticmethod
     @_custom_fwd
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, batches):
         lib = load_library()
         x = x.contiguous()
         B, C, H, W = x.shape
@@ -469,8 +470,8 @@ class _BatchNormTrain(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _check(lib, lib.danra_batchnorm_train_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean),
                                                       _ptr(save_rstd), _ptr(running_mean), _ptr(running_var), B, C, H * W,
-                                                      ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _stream()),
-                   "danra_batchnorm_train_fwd")
+                                                      ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _ptr(batches),
+                                                      _stream()), "danra_batchnorm_train_fwd")
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, y if relu else None, gamma, save_mean, save_rstd)
         return y
@@ -488,7 +489,7 @@ class _BatchNormTrain(torch.autograd.Function):
             _check(lib, lib.danra_batchnorm_train_bwd(_ptr(x), _ptr(dy), _ptr(y), _ptr(gamma), _ptr(save_mean),
                                                       _ptr(save_rstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), B, C, H * W,
                                                       int(ctx.relu), _stream()), "danra_batchnorm_train_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _BatchNormAddReluTrain(torch.autograd.Function):
@@ -497,7 +498,7 @@ class _BatchNormAddReluTrain(torch.autograd.Function):
 
     @staticmethod
     @_custom_fwd
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, batches):
         lib = load_library()
         x, res = x.contiguous(), res.contiguous()
         B, C, H, W = x.shape
@@ -508,7 +509,7 @@ class _BatchNormAddReluTrain(torch.autograd.Function):
             _check(lib, lib.danra_batchnorm_train_add_relu_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y),
                                                                _ptr(save_mean), _ptr(save_rstd), _ptr(running_mean),
                                                                _ptr(running_var), B, C, H * W, ctypes.c_float(eps),
-                                                               ctypes.c_float(momentum), _stream()),
+                                                               ctypes.c_float(momentum), _ptr(batches), _stream()),
                    "danra_batchnorm_train_add_relu_fwd")
         ctx.save_for_backward(x, y, gamma, save_mean, save_rstd)
         return y
@@ -526,16 +527,26 @@ class _BatchNormAddReluTrain(torch.autograd.Function):
             _check(lib, lib.danra_batchnorm_train_add_relu_bwd(_ptr(x), _ptr(dy), _ptr(y), _ptr(gamma), _ptr(save_mean),
                                                                _ptr(save_rstd), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta),
                                                                B, C, H * W, _stream()), "danra_batchnorm_train_add_relu_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
+
+
+def _batch_counter(bn):
+    """bn.num_batches_tracked where the kernel can increment it (an int64 scalar on the device), else it is incremented
+    here and None is returned."""
+    n = bn.num_batches_tracked
+    if n is not None and n.is_cuda and n.dtype == torch.int64 and n.numel() == 1 and n.is_contiguous():
+        return n
+    if n is not None:
+        with torch.no_grad():
+            n.add_(1)
+    return None
 
 
 def batchnorm_add_relu_train(bn, x, res):
     """relu(bn(x) + res) for a train-mode nn.BatchNorm2d through the native kernel (see batchnorm_train_supported; `res` has
     x's shape)."""
-    with torch.no_grad():
-        bn.num_batches_tracked.add_(1)
     return _BatchNormAddReluTrain.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                                        float(bn.momentum))
+                                        float(bn.momentum), _batch_counter(bn))
 
 
 def batchnorm_train_supported(bn, x):
@@ -550,10 +561,8 @@ def batchnorm_train_supported(bn, x):
 
 def batchnorm_train(bn, x, relu=False):
     """bn(x) [then ReLU] for a train-mode nn.BatchNorm2d through the native kernels (see batchnorm_train_supported)."""
-    with torch.no_grad():
-        bn.num_batches_tracked.add_(1)
     return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                                 float(bn.momentum), bool(relu))
+                                 float(bn.momentum), bool(relu), _batch_counter(bn))
 
 
 class _InstanceNorm(torch.autograd.Function):

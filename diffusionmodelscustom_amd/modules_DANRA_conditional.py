@@ -98,6 +98,18 @@ def _time_projections(time_embedding, channels):
     return nn.ModuleList([nn.Sequential(nn.SiLU(), nn.Linear(time_embedding, ch)) for ch in channels])
 
 
+def _shared_activation(projections, emb):
+    """``SiLU(emb)`` evaluated once for several ``Sequential(SiLU, Linear)`` time projections that all read the same
+    embedding (each then applies only its Linear: the same arithmetic with one activation kernel instead of one per
+    level); None when a projection is built differently or carries forward hooks, and the caller runs the modules whole."""
+    for p in projections:
+        if not (type(p) is nn.Sequential and len(p) == 2 and type(p[0]) is nn.SiLU and not p[0].inplace
+                and not p._forward_hooks and not p._forward_pre_hooks and not p[0]._forward_hooks
+                and not p[0]._forward_pre_hooks):
+            return None
+    return nn.functional.silu(emb)
+
+
 class Encoder(ResNet):
     """ResNet-18 encoder with a time bias and self-attention after every stage (reference modules:117-345)."""
 
@@ -169,8 +181,11 @@ class Encoder(ResNet):
         if y is not None:
             emb = emb + self.label_emb(y)
 
+        act = _shared_activation(self.time_projection_layers, emb)
+
         def stage(level, fmap):
-            fmap = fmap + self.time_projection_layers[level](emb)[:, :, None, None]
+            proj = self.time_projection_layers[level]
+            fmap = fmap + (proj(emb) if act is None else proj[1](act))[:, :, None, None]
             return self.attention_layers[level](fmap)
 
         fmap1 = stage(0, conv2d(self.conv1, x))   # (the training step's stem convolutions run in the native library)
@@ -229,7 +244,10 @@ class DecoderBlock(nn.Module):
     def shape_mismatch_message(prev_fmap, out):
         return 'feature maps must be of same shape'
 
-    def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None):
+    def forward(self, fmap: torch.Tensor, prev_fmap: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None,
+                t_act: Optional[torch.Tensor] = None):
+        """``t_act``: SiLU of this block's sinusoidal embedding of ``t`` where the caller has formed it already (the
+        decoder forms it once for its blocks, whose embeddings are the same parameter-free function)."""
         if fmap.is_cuda:  # up-sampling, the two norms and the convolution run in the native library where it has them
             from .hip_engine import conv2d, conv_transpose2d, instance_norm
             up = conv_transpose2d(self.transpose, fmap)
@@ -242,7 +260,8 @@ class DecoderBlock(nn.Module):
             assert (prev_fmap.shape == out.shape), self.shape_mismatch_message(prev_fmap, out)
             out = out + prev_fmap
         if torch.is_tensor(t):
-            t_emb = self.time_projection_layer(self.sinusiodal_embedding(t))
+            t_emb = (self.time_projection_layer(self.sinusiodal_embedding(t)) if t_act is None
+                     else self.time_projection_layer[1](t_act))
             out = self.attention(out + t_emb[:, :, None, None])
         return self.activation(out)
 
@@ -280,8 +299,16 @@ class Decoder(nn.Module):
     def forward(self, *fmaps, t: Optional[torch.Tensor] = None):
         deepest_first = list(reversed(fmaps))
         out = deepest_first[0]
-        for idx, block in enumerate(self.residual_layers):
-            out = block(out, deepest_first[idx + 1], t)
+        t_act = None
+        blocks = list(self.residual_layers)
+        if torch.is_tensor(t) and blocks:
+            first = blocks[0].sinusiodal_embedding
+            if all(type(b.sinusiodal_embedding) is SinusoidalEmbedding and not b.sinusiodal_embedding._forward_hooks
+                   and (b.sinusiodal_embedding.dim_size, b.sinusiodal_embedding.n) == (first.dim_size, first.n)
+                   for b in blocks):
+                t_act = _shared_activation([b.time_projection_layer for b in blocks], first(t))
+        for idx, block in enumerate(blocks):
+            out = block(out, deepest_first[idx + 1], t) if t_act is None else block(out, deepest_first[idx + 1], t, t_act)
         return self.final_layer(out)
 
 

@@ -199,10 +199,12 @@ int danra_attention_small_bwd(const float* q_dev, const float* k_dev, const floa
  * statistics per channel over (B, H, W), y = (x - mean) / sqrt(var_biased + eps) * gamma + beta, optionally followed by the
  * ReLU that every such norm of the network except bn2 is followed by; running_mean / running_var (may both be NULL) move by
  * `momentum` towards the batch mean / unbiased batch variance.  x, y: NCHW fp32 [B][C][HW] contiguous, HW a multiple
- * of 4; save_mean / save_rstd: [C], kept for the backward pass. */
+ * of 4; save_mean / save_rstd: [C], kept for the backward pass; num_batches_tracked_dev (may be NULL): the module's int64
+ * counter of that name, incremented by one on the device (torch.nn.modules.batchnorm._BatchNorm.forward does so per call). */
 int danra_batchnorm_train_fwd(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                               float* save_mean_dev, float* save_rstd_dev, float* running_mean_dev, float* running_var_dev,
-                              int B, int C, int HW, float eps, float momentum, int relu, void* stream);
+                              int B, int C, int HW, float eps, float momentum, int relu, long long* num_batches_tracked_dev,
+                              void* stream);
 /* Its autograd backward: dy -> dx, dgamma, dbeta.  y_dev (the forward's output) is read only when relu != 0. */
 int danra_batchnorm_train_bwd(const float* x_dev, const float* dy_dev, const float* y_dev, const float* gamma_dev,
                               const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dgamma_dev,
@@ -213,7 +215,8 @@ int danra_batchnorm_train_bwd(const float* x_dev, const float* dy_dev, const flo
  * dbeta as danra_batchnorm_train_bwd for that masked gradient.  Same shapes and restrictions as danra_batchnorm_train_fwd. */
 int danra_batchnorm_train_add_relu_fwd(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
                                        float* y_dev, float* save_mean_dev, float* save_rstd_dev, float* running_mean_dev,
-                                       float* running_var_dev, int B, int C, int HW, float eps, float momentum, void* stream);
+                                       float* running_var_dev, int B, int C, int HW, float eps, float momentum,
+                                       long long* num_batches_tracked_dev, void* stream);
 int danra_batchnorm_train_add_relu_bwd(const float* x_dev, const float* dy_dev, const float* y_dev, const float* gamma_dev,
                                        const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dres_dev,
                                        float* dgamma_dev, float* dbeta_dev, int B, int C, int HW, void* stream);

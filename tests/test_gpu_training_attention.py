@@ -651,7 +651,8 @@ def native_call_counters(monkeypatch):
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
              "danra_tokens_to_nchw_add", "danra_attention_small_fwd", "danra_attention_small_bwd",
-             "danra_conv3x3_c1_train_fwd", "danra_conv3x3_c1_train_dgrad", "danra_conv3x3_c1_train_wgrad")
+             "danra_conv3x3_c1_train_fwd", "danra_conv3x3_c1_train_dgrad", "danra_conv3x3_c1_train_wgrad",
+             "danra_conv8x8s2_train_fwd", "danra_conv8x8s2_train_dgrad", "danra_conv8x8s2_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
