@@ -53,16 +53,20 @@ def summarise(path, top, sequence=False, width=100):
     print(f"last replay: {len(last)} kernels, busy {busy / 1e3:.0f} us, wall {(ends[-1] - starts[cut]) / 1e3:.0f} us")
     for name, (ns, n) in sorted(total.items(), key=lambda kv: -kv[1][0])[:top]:
         print(f"{ns / 1e3:9.1f} us  x{n:<4d} {100 * ns / busy:5.1f} %  {name}")
-    if sequence:   # the replay's kernels in launch order, runs of one name collapsed
+    if sequence:   # the replay's kernels in launch order, runs of one name collapsed (time of the run, grid of its last launch)
         print("--- launch order")
-        run_name, run_n = None, 0
+        run_name, run_n, run_ns, grid = None, 0, 0, ""
         for r in last + [None]:
             name = None if r is None else r["Kernel_Name"][:70]
             if name != run_name:
                 if run_name is not None:
-                    print(f"  x{run_n:<4d} {run_name}")
-                run_name, run_n = name, 0
-            run_n += 1
+                    print(f"  x{run_n:<3d} {run_ns / 1e3:7.1f} us  {grid:>12s}  {run_name}")
+                run_name, run_n, run_ns = name, 0, 0
+            if r is not None:
+                run_n += 1
+                run_ns += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                wg = max(int(r.get("Workgroup_Size_X", 1) or 1), 1)
+                grid = "x".join(str(int(r.get(f"Grid_Size_{a}", 1) or 1) // (wg if a == "X" else 1)) for a in "XYZ")
 
 
 if __name__ == "__main__":
