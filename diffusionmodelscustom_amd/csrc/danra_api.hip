@@ -1380,6 +1380,21 @@ int danra_attention_core_bwd(const float* q, const float* k, const float* v, con
     return DANRA_OK;
 }
 
+int danra_attention_core_qkv_fwd(const float* qkv, float* out, float* lse2, int B, int heads, int L, int head_dim, void* stream) {
+    if (!qkv || !out) return fail(DANRA_EINVAL, "null argument");
+    if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
+    HIP_TRY(launch_attention_hd16_tokens(qkv, out, lse2, B, heads, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_attention_core_qkv_bwd(const float* qkv, const float* out, const float* dout, const float* lse2, float* dqkv,
+                                 float* delta, int B, int heads, int L, int head_dim, void* stream) {
+    if (!qkv || !out || !dout || !lse2 || !dqkv || !delta) return fail(DANRA_EINVAL, "null argument");
+    if (int rc = check_core_shape(B, heads, L, head_dim)) return rc;
+    HIP_TRY(launch_attention_hd16_bwd_tokens(qkv, out, dout, lse2, dqkv, delta, B, heads, L, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_attention_small_supported(int B, int heads, int L, int head_dim) {
     return attention_small_train_supported(B, heads, L, head_dim) ? 1 : 0;
 }

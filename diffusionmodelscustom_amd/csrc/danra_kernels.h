@@ -189,6 +189,14 @@ hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, f
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
                              const float* res, float* out, int M, int N, int K, int act, hipStream_t stream, int ct_H = 0,
                              int ct_W = 0, bool layernorm = false);
+// Where q, k, v of one (image, head) lie: rows `rs` floats apart, the pair (b, head) at b * img + head * hs floats.
+// [B*heads][L][16]: {16, heads * L * 16, L * 16}; the output of a fused QKV projection [B][L][3][heads * 16], read in
+// place: {3 * heads * 16, L * 3 * heads * 16, 16} with k = q + heads * 16, v = q + 2 * heads * 16.
+struct QkvLayout {
+    int rs;
+    long long img;
+    int hs;
+};
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
@@ -201,6 +209,11 @@ void set_attention_hd16_fp32_products(int on);
 hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                      const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads,
                                      int L, hipStream_t stream);
+
+// Both on the output of a fused QKV projection used in place (the training step's in_proj): qkv, dqkv [B][L][3][heads*16].
+hipError_t launch_attention_hd16_tokens(const float* qkv, float* out, float* lse2, int B, int heads, int L, hipStream_t stream);
+hipError_t launch_attention_hd16_bwd_tokens(const float* qkv, const float* out, const float* dout, const float* lse2,
+                                            float* dqkv, float* delta, int B, int heads, int L, hipStream_t stream);
 
 // ---------------------------------------------------------------- small kernels
 // Device-resident state of the sampling loop: one denoise step can be enqueued (or replayed from a

@@ -81,12 +81,16 @@ struct FlashPre {
     const float* v32;
     const int* flags;
 };
-template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH, int KT64 = 1, bool PRE = false>
+// TOK: Q, K and V are read where a fused QKV projection leaves them - rows of one (image, head) lay.rs floats apart, the
+// (image, head) pair at b * lay.img + head * lay.hs - instead of [n_bh][L][16] (the training step's in_proj output
+// [B][L][3][heads * 16] is then used in place: rs = 3 heads 16, img = L rs, hs = 16, and K, V = Q + heads 16, + 2 heads 16).
+template <int QT, int ABL = 0, bool PVH = true, bool QKH = PVH, int KT64 = 1, bool PRE = false, bool TOK = false>
 __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, float* __restrict__ O,
                                                     float* __restrict__ LSE2, int L, int heads, int n_bh,
-                                                    float scale_log2e, const FlashPre pre) {
+                                                    float scale_log2e, const FlashPre pre, const QkvLayout lay) {
     static_assert(!PRE || (PVH && QKH && KT64 == 1), "pre-split operands: the fp16 form, 64 keys per tile");
+    static_assert(!(PRE && TOK), "pre-split operands have their own layout");
     // fp32 tiles only in the all-fp32 form; the fp32 fallback of the fp16 forms (rare) reads global memory instead
     constexpr bool F32_TILES = !(PVH && QKH);
     __shared__ __attribute__((aligned(16))) float Ks[F32_TILES ? 2 : 1][F32_TILES ? KT64 * KVT * KROW : 4];
@@ -121,14 +125,16 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     const int lq = lane & 15;  // query column / key row / d column, depending on the operand
     const int g = lane >> 4;   // k-slot of the MFMA
 
-    const float* Qb = Q + (size_t)bh * L * 16;
-    const float* Kb = K + (size_t)bh * L * 16;
-    const float* Vb = V + (size_t)bh * L * 16;
+    const int RS = TOK ? lay.rs : 16;   // floats between two rows of an operand
+    const size_t base = TOK ? (size_t)(bh / heads) * lay.img + (size_t)(bh % heads) * lay.hs : (size_t)bh * L * 16;
+    const float* Qb = Q + base;
+    const float* Kb = K + base;
+    const float* Vb = V + base;
 
     // Q fragments: B operand of S^T = K Q^T: lane (q, g) holds Q[q][4g + r] for MFMA step r.
     // Q is pre-multiplied by hd^-1/2 * log2(e): scores come out of the matrix cores in the exp2 domain.
     auto load_qf = [&](int t) {
-        float4 f = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+        float4 f = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * RS + 4 * g);
         f.x *= scale_log2e;
         f.y *= scale_log2e;
         f.z *= scale_log2e;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
     if (QKH) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float4 qa = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * 16 + 4 * g);
+            const float4 qa = *reinterpret_cast<const float4*>(Qb + (size_t)(q0 + t * 16 + lq) * RS + 4 * g);
             const float qq[4] = {qa.x, qa.y, qa.z, qa.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -202,12 +208,12 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
         }
 #pragma unroll
         for (int u = 0; u < KT64; ++u) {
-            kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(tile * TK + KVT * u + srow) * 16 + sc4);
+            kreg[u] = *reinterpret_cast<const float4*>(Kb + (size_t)(tile * TK + KVT * u + srow) * RS + sc4);
             if (PVH) {
-                const float* vp = Vb + (size_t)(tile * TK + KVT * u + vkey) * 16 + vd;
-                vreg[u] = make_float4(vp[0], vp[16], vp[32], vp[48]);
+                const float* vp = Vb + (size_t)(tile * TK + KVT * u + vkey) * RS + vd;
+                vreg[u] = make_float4(vp[0], vp[RS], vp[2 * RS], vp[3 * RS]);
             } else {
-                vreg[u] = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * TK + KVT * u + srow) * 16 + sc4);
+                vreg[u] = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * TK + KVT * u + srow) * RS + sc4);
             }
         }
     };
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 } else {
                     kf = F32_TILES
                         ? *reinterpret_cast<const float4*>(&Ks[buf][((2 * hf + j) * 16 + lq) * KROW + 4 * g])
-                        : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * TK + (2 * hf + j) * 16 + lq) * 16 + 4 * g);
+                        : *reinterpret_cast<const float4*>(Kb + (size_t)(kt * TK + (2 * hf + j) * 16 + lq) * RS + 4 * g);
                 }
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16(const float* __restrict__ Q,
                 for (int r = 0; r < 4; ++r)
                     vf[r] = (ABL & 2) ? scale_log2e + (float)r
                           : F32_TILES ? Vs[buf][((2 * hf + j) * 16 + 4 * g + r) * KROW + lq]
-                                      : Vb[(size_t)(kt * TK + (2 * hf + j) * 16 + 4 * g + r) * 16 + lq];
+                                      : Vb[(size_t)(kt * TK + (2 * hf + j) * 16 + 4 * g + r) * RS + lq];
                 }
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
@@ -1553,7 +1559,7 @@ hipError_t launch_attention_hd16_pre(const float* q, const float* ks, const floa
     const FlashPre pre{k32, v32, flags};
     float* no_lse = nullptr;
     DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, true, true, 1, true>), grid, dim3(256), 0, stream, q, ks, vs, out, no_lse, L, heads,
-                       B * heads, scale_log2e, pre);
+                       B * heads, scale_log2e, pre, QkvLayout{});
     return hipGetLastError();
 }
 
@@ -1568,9 +1574,28 @@ hipError_t launch_attention_hd16(const float* q, const float* k, const float* v,
     const FlashPre no_pre{nullptr, nullptr, nullptr};
     if (g_hd16_fp32_products)
         DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, false, false>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads,
-                           B * heads, scale_log2e, no_pre);
+                           B * heads, scale_log2e, no_pre, QkvLayout{});
     else
-        DANRA_LAUNCH_KERNEL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e, no_pre);
+        DANRA_LAUNCH_KERNEL(k_flash_hd16<2>, grid, dim3(256), 0, stream, q, k, v, out, lse2, L, heads, B * heads, scale_log2e, no_pre,
+                           QkvLayout{});
+    return hipGetLastError();
+}
+
+// the same core on the output of a fused QKV projection, used in place: qkv [B][L][3][heads * 16]
+hipError_t launch_attention_hd16_tokens(const float* qkv, float* out, float* lse2, int B, int heads, int L, hipStream_t stream) {
+    if (L % 128 != 0) return hipErrorInvalidValue;
+    const float scale_log2e = 0.25f * 1.4426950408889634f;
+    dim3 grid((L / 128) * B * heads);
+    const FlashPre no_pre{nullptr, nullptr, nullptr};
+    const int C = heads * 16;
+    const QkvLayout lay{3 * C, (long long)L * 3 * C, 16};
+    const float *q = qkv, *k = qkv + C, *v = qkv + 2 * C;
+    if (g_hd16_fp32_products)
+        DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, false, false, 1, false, true>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L,
+                           heads, B * heads, scale_log2e, no_pre, lay);
+    else
+        DANRA_LAUNCH_KERNEL((k_flash_hd16<2, 0, true, true, 1, false, true>), grid, dim3(256), 0, stream, q, k, v, out, lse2, L,
+                           heads, B * heads, scale_log2e, no_pre, lay);
     return hipGetLastError();
 }
 

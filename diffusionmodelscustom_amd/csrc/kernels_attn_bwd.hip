@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
                                                            const float* __restrict__ V, const float* __restrict__ O,
                                                            const float* __restrict__ dO, const float* __restrict__ LSE2,
                                                            float* __restrict__ dQ, float* __restrict__ Dout, int L,
-                                                           int heads, int n_bh, float scale) {
+                                                           int heads, int n_bh, float scale, const QkvLayout lay) {
     __shared__ __attribute__((aligned(16))) float Ks[2][BT * BROW];
     __shared__ __attribute__((aligned(16))) float Vs[2][BT * BROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,9 +62,11 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
     const int b = bh / heads, head = bh - b * heads, C = heads * 16;
     const float scale_log2e = scale * 1.4426950408889634f;
 
-    const float* Qb = Q + (size_t)bh * L * 16;
-    const float* Kb = K + (size_t)bh * L * 16;
-    const float* Vb = V + (size_t)bh * L * 16;
+    const int RS = lay.rs;   // floats between two rows of q, k, v, dq (16, or the row of a fused QKV projection)
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    const float* Qb = Q + base;
+    const float* Kb = K + base;
+    const float* Vb = V + base;
 
     // resident operands of the wave's queries: lane (q, g) holds columns 4g .. 4g+3 of row q
     float4 qf[QT], dof[QT];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0 + t * 16 + lq;
-        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)q * 16 + 4 * g);
+        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)q * RS + 4 * g);
         qf[t].x *= scale_log2e; qf[t].y *= scale_log2e; qf[t].z *= scale_log2e; qf[t].w *= scale_log2e;
         const size_t tok = ((size_t)b * L + q) * C + head * 16 + 4 * g;
         dof[t] = *reinterpret_cast<const float4*>(dO + tok);
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
     }
 
     const int srow = tid >> 2, sc4 = (tid & 3) * 4;
-    float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * 16 + sc4);
-    float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * 16 + sc4);
+    float4 kreg = *reinterpret_cast<const float4*>(Kb + (size_t)srow * RS + sc4);
+    float4 vreg = *reinterpret_cast<const float4*>(Vb + (size_t)srow * RS + sc4);
     *reinterpret_cast<float4*>(&Ks[0][srow * BROW + sc4]) = kreg;
     *reinterpret_cast<float4*>(&Vs[0][srow * BROW + sc4]) = vreg;
     __syncthreads();
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
         const int buf = kt & 1;
         {   // unconditional prefetch (the last tile re-reads itself)
             const int nxt = min(kt + 1, ntiles - 1);
-            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * BT + srow) * 16 + sc4);
-            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * BT + srow) * 16 + sc4);
+            kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(nxt * BT + srow) * RS + sc4);
+            vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(nxt * BT + srow) * RS + sc4);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // 16 keys at a time
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float4 o = make_float4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
-        *reinterpret_cast<float4*>(dQ + ((size_t)bh * L + q0 + t * 16 + lq) * 16 + 4 * g) = o;
+        *reinterpret_cast<float4*>(dQ + base + (size_t)(q0 + t * 16 + lq) * RS + 4 * g) = o;
     }
 }
 
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
                                                             const float* __restrict__ V, const float* __restrict__ dO,
                                                             const float* __restrict__ LSE2, const float* __restrict__ D,
                                                             float* __restrict__ dK, float* __restrict__ dV, int L,
-                                                            int heads, int n_bh, float scale) {
+                                                            int heads, int n_bh, float scale, const QkvLayout lay) {
     __shared__ __attribute__((aligned(16))) float Qs[2][BT * BROW];
     __shared__ __attribute__((aligned(16))) float dOs[2][BT * BROW];
     __shared__ __attribute__((aligned(16))) float NLs[2][BT];  // -LSE2 of the tile's queries
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
     const int b = bh / heads, head = bh - b * heads, C = heads * 16;
     const float scale_log2e = scale * 1.4426950408889634f;
 
-    const float* Qb = Q + (size_t)bh * L * 16;
+    const int RS = lay.rs;
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    const float* Qb = Q + base;
     const float* dOb = dO + (size_t)b * L * C + head * 16;
     const float* Lb = LSE2 + (size_t)bh * L;
     const float* Db = D + (size_t)bh * L;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
     f32x4 dk[KT], dv[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const size_t row = ((size_t)bh * L + k0 + t * 16 + lq) * 16 + 4 * g;
+        const size_t row = base + (size_t)(k0 + t * 16 + lq) * RS + 4 * g;
         kf[t] = *reinterpret_cast<const float4*>(K + row);
         kf[t].x *= scale_log2e; kf[t].y *= scale_log2e; kf[t].z *= scale_log2e; kf[t].w *= scale_log2e;
         vf[t] = *reinterpret_cast<const float4*>(V + row);
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
 
     // staging: 64 queries x 16 floats of Q and dO (one float4 each per thread); -LSE2 and -D by the first 64 threads
     const int srow = tid >> 2, sc4 = (tid & 3) * 4, r64 = tid & 63;
-    float4 qreg = *reinterpret_cast<const float4*>(Qb + (size_t)srow * 16 + sc4);
+    float4 qreg = *reinterpret_cast<const float4*>(Qb + (size_t)srow * RS + sc4);
     float4 doreg = *reinterpret_cast<const float4*>(dOb + (size_t)srow * C + sc4);
     float lreg = Lb[r64], dreg = Db[r64];
     *reinterpret_cast<float4*>(&Qs[0][srow * BROW + sc4]) = qreg;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
         const int buf = qt & 1;
         {
             const int nxt = min(qt + 1, ntiles - 1);
-            qreg = *reinterpret_cast<const float4*>(Qb + (size_t)(nxt * BT + srow) * 16 + sc4);
+            qreg = *reinterpret_cast<const float4*>(Qb + (size_t)(nxt * BT + srow) * RS + sc4);
             doreg = *reinterpret_cast<const float4*>(dOb + (size_t)(nxt * BT + srow) * C + sc4);
             lreg = Lb[nxt * BT + r64];
             dreg = Db[nxt * BT + r64];
@@ -235,25 +239,40 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
     // lane (key, g) holds dK[key][4g .. 4g+3] and dV[key][4g .. 4g+3]
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const size_t row = ((size_t)bh * L + k0 + t * 16 + lq) * 16 + 4 * g;
+        const size_t row = base + (size_t)(k0 + t * 16 + lq) * RS + 4 * g;
         *reinterpret_cast<float4*>(dK + row) = make_float4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
         *reinterpret_cast<float4*>(dV + row) = make_float4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
     }
 }
 
-hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
-                                     const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads,
-                                     int L, hipStream_t stream) {
+static hipError_t launch_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                             const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads, int L,
+                             const QkvLayout lay, hipStream_t stream) {
     if (L % 128 != 0) return hipErrorInvalidValue;
     const float scale = 0.25f;  // head_dim^-1/2
     const dim3 grid((L / 128) * B * heads);
     hipLaunchKernelGGL(k_flash_hd16_bwd_dq<2>, grid, dim3(256), 0, stream, q, k, v, o, dout, lse2, dq, delta, L, heads,
-                       B * heads, scale);
+                       B * heads, scale, lay);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_flash_hd16_bwd_dkv<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
-                       B * heads, scale);
+                       B * heads, scale, lay);
     return hipGetLastError();
+}
+
+hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                     const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads,
+                                     int L, hipStream_t stream) {
+    return launch_bwd(q, k, v, o, dout, lse2, dq, dk, dv, delta, B, heads, L,
+                      QkvLayout{16, (long long)heads * L * 16, L * 16}, stream);
+}
+
+// q, k, v read from, and dq, dk, dv written to, the layout of a fused QKV projection: qkv, dqkv [B][L][3][heads * 16]
+hipError_t launch_attention_hd16_bwd_tokens(const float* qkv, const float* o, const float* dout, const float* lse2,
+                                            float* dqkv, float* delta, int B, int heads, int L, hipStream_t stream) {
+    const int C = heads * 16;
+    return launch_bwd(qkv, qkv + C, qkv + 2 * C, o, dout, lse2, dqkv, dqkv + C, dqkv + 2 * C, delta, B, heads, L,
+                      QkvLayout{3 * C, (long long)L * 3 * C, 16}, stream);
 }
 
 }  // namespace danra

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "danra_attention_small_supported": (ctypes.c_int, [ctypes.c_int] * 4),
     "danra_attention_small_fwd": (ctypes.c_int, [_P] * 4 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_small_bwd": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
+    "danra_attention_core_qkv_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
+    "danra_attention_core_qkv_bwd": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _P]),
     "danra_batchnorm_train_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -279,6 +281,45 @@ class _AttentionCoreHD16(torch.autograd.Function):
         return dqkv
 
 
+class _AttentionCoreHD16Qkv(torch.autograd.Function):
+    """The same core on the fused QKV projection's output used in place (danra_attention_core_qkv_fwd / _bwd): qkv
+    [B, L, 3 * heads * 16] contiguous, as nn.MultiheadAttention's in_proj leaves it -> tokens [B, L, heads*16]; the gradient
+    comes back in the same [B, L, 3 * heads * 16] layout, ready for the projection's backward - no copy into per-head tensors
+    in either direction."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, qkv, heads):
+        lib = load_library()
+        qkv = qkv.contiguous()
+        B, L, C3 = qkv.shape
+        hd = C3 // (3 * heads)
+        out = torch.empty((B, L, heads * hd), device=qkv.device, dtype=torch.float32)
+        lse2 = torch.empty((B * heads, L), device=qkv.device, dtype=torch.float32)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_core_qkv_fwd(_ptr(qkv), _ptr(out), _ptr(lse2), B, heads, L, hd, _stream()),
+                   "danra_attention_core_qkv_fwd")
+        ctx.save_for_backward(qkv, out, lse2)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        lib = load_library()
+        qkv, out, lse2 = ctx.saved_tensors
+        B, L, C3 = qkv.shape
+        heads = ctx.heads
+        dout = _f32(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse2)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_core_qkv_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse2), _ptr(dqkv), _ptr(delta),
+                                                         B, heads, L, C3 // (3 * heads), _stream()),
+                   "danra_attention_core_qkv_bwd")
+        return dqkv, None
+
+
 class _AttentionCoreSmall(torch.autograd.Function):
     """softmax(q k^T / sqrt(head_dim)) v per head for the short sequences of the deep levels (at most 64 tokens, head_dim up
     to 128), forward and backward in libdanra_hip.so (danra_attention_small_fwd / _bwd): one workgroup per (image, head),
@@ -425,15 +466,16 @@ def token_linear(x, weight, bias):
 def differentiable_self_attention(mha, tokens):
     """nn.MultiheadAttention(tokens, tokens, tokens, need_weights=False)[0] for a batch_first, dropout-free module: the
     two projections through token_linear, the scaled-dot-product core in the native library where it has the shape
-    (attention_core_supported: head_dim 16, the 64-channel levels; attention_small_supported: the short sequences of the
-    deep levels) and torch's fused scaled_dot_product_attention otherwise."""
+    (attention_core_supported: head_dim 16, the 64-channel levels - there the core reads the projection's output where it
+    lies; attention_small_supported: the short sequences of the deep levels) and torch's fused scaled_dot_product_attention otherwise."""
     B, L, C = tokens.shape
     heads = mha.num_heads
     qkv = token_linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
-    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
     if attention_core_supported(tokens, heads):
-        attended = _AttentionCoreHD16.apply(qkv)  # (made contiguous and float32 by the core)
-    elif attention_small_supported(tokens, heads):
+        attended = _AttentionCoreHD16Qkv.apply(qkv, heads)  # the projection's [B, L, 3 C] output in place
+        return token_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
+    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
+    if attention_small_supported(tokens, heads):
         attended = _AttentionCoreSmall.apply(qkv)
     else:
         attended = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])

@@ -184,6 +184,14 @@ int danra_set_fp32_products(int fp32_products);
 int danra_attention_core_bwd(const float* q_dev, const float* k_dev, const float* v_dev, const float* out_dev,
                              const float* dout_dev, const float* lse2_dev, float* dq_dev, float* dk_dev, float* dv_dev,
                              float* delta_dev, int B, int heads, int L, int head_dim, void* stream);
+/* The same core, forward and backward, on the output of the block's fused QKV projection used in place (no copy into
+ * per-head tensors): qkv_dev, dqkv_dev [B][L][3][heads*16] - what nn.MultiheadAttention's in_proj produces for batch_first
+ * tokens (torch.nn.functional.multi_head_attention_forward's _in_projection_packed) - q of head h at columns 16h .. 16h+15
+ * of part 0, k and v in parts 1 and 2.  out, dout, lse2, delta as above. */
+int danra_attention_core_qkv_fwd(const float* qkv_dev, float* out_dev, float* lse2_dev, int B, int heads, int L, int head_dim,
+                                 void* stream);
+int danra_attention_core_qkv_bwd(const float* qkv_dev, const float* out_dev, const float* dout_dev, const float* lse2_dev,
+                                 float* dqkv_dev, float* delta_dev, int B, int heads, int L, int head_dim, void* stream);
 
 /* The scaled-dot-product core of the short-sequence attention blocks in a training step (the deep levels: nn.MultiheadAttention
  * between its in- and out-projection, modules:100-107, at 64 / 16 / 4 tokens with head_dim 32 / 64 / 128): softmax(q k^T /

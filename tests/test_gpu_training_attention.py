@@ -45,6 +45,24 @@ def run_core(q, k, v, dout):
     return out.cpu(), dq.cpu(), dk.cpu(), dv.cpu(), lse2.cpu()
 
 
+def run_core_qkv(q, k, v, dout):
+    """The same core on the layout of the block's fused QKV projection, [B][L][3][heads*16], read and written in place."""
+    lib = hip_engine.load_library()
+    B, heads, L, hd = q.shape
+    qkv = torch.stack([t.permute(0, 2, 1, 3).reshape(B, L, heads * hd) for t in (q, k, v)], dim=2).to(DEV).contiguous()
+    dd = dout.to(DEV).contiguous()
+    out = torch.empty((B, L, heads * hd), device=DEV)
+    lse2 = torch.empty((B * heads, L), device=DEV)
+    delta = torch.empty_like(lse2)
+    dqkv = torch.full_like(qkv, float("nan"))
+    _check(lib, lib.danra_attention_core_qkv_fwd(_ptr(qkv), _ptr(out), _ptr(lse2), B, heads, L, hd, _stream()), "qkv fwd")
+    _check(lib, lib.danra_attention_core_qkv_bwd(_ptr(qkv), _ptr(out), _ptr(dd), _ptr(lse2), _ptr(dqkv), _ptr(delta), B, heads,
+                                                 L, hd, _stream()), "qkv bwd")
+    torch.cuda.synchronize()
+    dq, dk, dv = (dqkv[:, :, i].reshape(B, L, heads, hd).permute(0, 2, 1, 3).contiguous().cpu() for i in range(3))
+    return out.cpu(), dq, dk, dv, lse2.cpu()
+
+
 def run_core_presplit(q, k, v):
     """The same core as the network's inference path runs it: K and V pre-split by their producer."""
     lib = hip_engine.load_library()
@@ -201,6 +219,28 @@ def test_core_is_deterministic_and_rejects_other_shapes():
                                         _ptr(x), 1, 1, 128, 16, _stream()) == -1                                   # null
 
 
+@pytest.mark.parametrize("B,heads,L,fp32", [(2, 4, 256, 0), (3, 4, 1024, 0), (3, 2, 128, 0), (2, 4, 256, 1)])
+def test_core_on_the_projection_layout_equals_the_per_head_layout(B, heads, L, fp32):
+    """danra_attention_core_qkv_fwd / _bwd read q, k, v from - and write their gradients into - the [B][L][3][heads*16]
+    layout of nn.MultiheadAttention's fused in_proj; the arithmetic is that of danra_attention_core_fwd / _bwd on per-head
+    tensors, so every output agrees bit for bit (both product forms), values that leave the fp16 range included."""
+    g = torch.Generator().manual_seed(77 + L)
+    q = torch.randn(B, heads, L, 16, generator=g) * 3
+    k = torch.randn(B, heads, L, 16, generator=g)
+    v = torch.randn(B, heads, L, 16, generator=g) * 2 + 0.5
+    v[0, 1, 40:48] *= 1e6          # a tile of values beyond the split-operand range
+    dout = torch.randn(B, L, heads * 16, generator=g)
+    lib = hip_engine.load_library()
+    lib.danra_set_fp32_products(fp32)
+    try:
+        want = run_core(q, k, v, dout)
+        got = run_core_qkv(q, k, v, dout)
+    finally:
+        lib.danra_set_fp32_products(0)
+    for a, b, what in zip(got, want, ("out", "dq", "dk", "dv", "lse2")):
+        assert torch.equal(a, b), f"{what} differs between the two layouts"
+
+
 @pytest.mark.parametrize("scale", [1.0, 2.5])
 def test_core_forward_is_reproducible_on_self_similar_peaked_rows(scale):
     """q = k = v on a coarse grid: every row is dominated by its own key, rows move their softmax reference at
@@ -251,7 +291,7 @@ def test_attention_block_gradients_match_torch_module(monkeypatch):
 
     gpu = copy.deepcopy(block).to(DEV)
     gpu.zero_grad()
-    fwd, bwd = count_calls(monkeypatch, "danra_attention_core_fwd"), count_calls(monkeypatch, "danra_attention_core_bwd")
+    fwd, bwd = count_calls(monkeypatch, "danra_attention_core_qkv_fwd"), count_calls(monkeypatch, "danra_attention_core_qkv_bwd")
     xg = x.to(DEV).requires_grad_(True)
     yg = gpu(xg)
     yg.backward(dy.to(DEV))
@@ -364,7 +404,7 @@ def test_training_step_gradients(builder, monkeypatch):
 
     lib = hip_engine.load_library()
     gpu = copy.deepcopy(model).to(DEV)
-    fwd, bwd = count_calls(monkeypatch, "danra_attention_core_fwd"), count_calls(monkeypatch, "danra_attention_core_bwd")
+    fwd, bwd = count_calls(monkeypatch, "danra_attention_core_qkv_fwd"), count_calls(monkeypatch, "danra_attention_core_qkv_bwd")
     decisions = record_relu_decisions(monkeypatch, gpu)
     report = {}
     try:
@@ -645,7 +685,7 @@ def test_attention_block_entry_and_exit_match_float64(B, C, H, W):
 
 
 def native_call_counters(monkeypatch):
-    names = ("danra_attention_core_fwd", "danra_attention_core_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
+    names = ("danra_attention_core_qkv_fwd", "danra_attention_core_qkv_bwd", "danra_batchnorm_train_fwd", "danra_batchnorm_train_bwd",
              "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd",
              "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd", "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
@@ -662,7 +702,7 @@ def native_call_counters(monkeypatch):
 # has stride 2 and goes through the stride-1 kernels) and the four decoder blocks' (the final block's has one output
 # channel and kernels of its own), each in three directions; the cores of the five attention blocks at 128 channels and more
 EXPECTED_NATIVE_CALLS = {"danra_conv3x3_c1_train_fwd": 1, "danra_conv3x3_c1_train_dgrad": 1, "danra_conv3x3_c1_train_wgrad": 1,
-                         "danra_attention_core_fwd": 4, "danra_attention_core_bwd": 4, "danra_attention_small_fwd": 5,
+                         "danra_attention_core_qkv_fwd": 4, "danra_attention_core_qkv_bwd": 4, "danra_attention_small_fwd": 5,
                          "danra_attention_small_bwd": 5, "danra_batchnorm_train_fwd": 12,
                          "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
