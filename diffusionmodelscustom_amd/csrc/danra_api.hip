@@ -1419,6 +1419,25 @@ int danra_attention_small_bwd(const float* q, const float* k, const float* v, co
     return DANRA_OK;
 }
 
+int danra_attention_small_qkv_fwd(const float* qkv, float* out, int B, int heads, int L, int head_dim, void* stream) {
+    if (!qkv || !out) return fail(DANRA_EINVAL, "null argument");
+    if (!attention_small_train_supported(B, heads, L, head_dim))
+        return fail(DANRA_EINVAL, "B=%d heads=%d L=%d head_dim=%d: not a shape of the short-sequence core (danra_attention_small_supported)",
+                    B, heads, L, head_dim);
+    HIP_TRY(launch_attention_small_qkv_fwd(qkv, out, B, heads, L, head_dim, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_attention_small_qkv_bwd(const float* qkv, const float* dout, float* dqkv, int B, int heads, int L, int head_dim,
+                                  void* stream) {
+    if (!qkv || !dout || !dqkv) return fail(DANRA_EINVAL, "null argument");
+    if (!attention_small_train_supported(B, heads, L, head_dim))
+        return fail(DANRA_EINVAL, "B=%d heads=%d L=%d head_dim=%d: not a shape of the short-sequence core (danra_attention_small_supported)",
+                    B, heads, L, head_dim);
+    HIP_TRY(launch_attention_small_qkv_bwd(qkv, dout, dqkv, B, heads, L, head_dim, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                               float* save_rstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
                               float momentum, int relu, long long* num_batches_tracked, void* stream) {

@@ -127,6 +127,14 @@ hipError_t launch_conv_c1_train_fwd(const float* x, const float* w, float* y, in
 hipError_t launch_conv_c1_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, hipStream_t stream);
 hipError_t launch_conv_c1_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, float* workspace,
                                       hipStream_t stream);
+// Where q, k, v of one (image, head) lie: rows `rs` floats apart, the pair (b, head) at b * img + head * hs floats.
+// [B*heads][L][16]: {16, heads * L * 16, L * 16}; the output of a fused QKV projection [B][L][3][heads * 16], read in
+// place: {3 * heads * 16, L * 3 * heads * 16, 16} with k = q + heads * 16, v = q + 2 * heads * 16.
+struct QkvLayout {
+    int rs;
+    long long img;
+    int hs;
+};
 // The 8x8 stride-2 padding-3 convolutions of the stem in a training step, NCHW fp32 (kernels_conv8_train.hip): x, dx
 // [B][Cin][H][W]; w, dw [Cout][Cin][8][8]; y, dy [B][Cout][H/2][W/2]; workspace: conv8s2_train_workspace_floats floats.
 bool conv8s2_train_supported(int B, int Cin, int Cout, int H, int W);
@@ -145,6 +153,10 @@ hipError_t launch_attention_small_fwd(const float* q, const float* k, const floa
                                       hipStream_t stream);
 hipError_t launch_attention_small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
                                       float* dv, int B, int heads, int L, int hd, hipStream_t stream);
+// both on the output of a fused QKV projection used in place: qkv, dqkv [B][L][3][heads*hd] (see QkvLayout)
+hipError_t launch_attention_small_qkv_fwd(const float* qkv, float* out, int B, int heads, int L, int hd, hipStream_t stream);
+hipError_t launch_attention_small_qkv_bwd(const float* qkv, const float* dout, float* dqkv, int B, int heads, int L, int hd,
+                                          hipStream_t stream);
 // K, V [n_bh][L][16] -> the pre-split form of the head_dim-16 core (ks, vs: as many bytes as k, v; flags: 2 * n_bh * L / 16
 // ints), and that core on it; k32 / v32 are read only where a flag is set (kernels_attn.hip, k_flash_hd16 PRE).
 hipError_t launch_presplit_kv(const float* k, const float* v, float* ks, float* vs, int* flags, int n_bh, int L,
@@ -189,14 +201,6 @@ hipError_t launch_frag16_from_f32(const float* w, float* out, int rows, int K, f
 hipError_t launch_proj_small(const float* a, const float* w_frag, const float* w, float wscale, const float* bias,
                              const float* res, float* out, int M, int N, int K, int act, hipStream_t stream, int ct_H = 0,
                              int ct_W = 0, bool layernorm = false);
-// Where q, k, v of one (image, head) lie: rows `rs` floats apart, the pair (b, head) at b * img + head * hs floats.
-// [B*heads][L][16]: {16, heads * L * 16, L * 16}; the output of a fused QKV projection [B][L][3][heads * 16], read in
-// place: {3 * heads * 16, L * 3 * heads * 16, 16} with k = q + heads * 16, v = q + 2 * heads * 16.
-struct QkvLayout {
-    int rs;
-    long long img;
-    int hs;
-};
 // head_dim 16, L a multiple of 128.  Forward as above; lse2 (may be null): [B*heads][L], the log-sum-exp of every
 // query's scaled scores in the exp2 domain, which the backward pass needs.
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,

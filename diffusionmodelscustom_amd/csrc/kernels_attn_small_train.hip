@@ -67,11 +67,12 @@ __device__ void scores_softmax(const float* Qs, const float* Ks, float* S, int L
     __syncthreads();
 }
 
-__device__ void load_rows(const float* src, float* dst, int L, int hd) {   // [L][hd] -> padded rows, four floats at a time
+// L rows of hd floats, `rs` floats apart -> padded rows, four floats at a time
+__device__ void load_rows(const float* src, float* dst, int L, int hd, int rs) {
     const int hq = hd >> 2;
     for (int e = threadIdx.x; e < L * hq; e += kSmallThreads) {
         const int i = e / hq, dq = e - i * hq;
-        *reinterpret_cast<float4*>(dst + i * pad(hd) + 4 * dq) = ld4(src + (size_t)i * hd + 4 * dq);
+        *reinterpret_cast<float4*>(dst + i * pad(hd) + 4 * dq) = ld4(src + (size_t)i * rs + 4 * dq);
     }
 }
 
@@ -81,15 +82,15 @@ __device__ void load_rows(const float* src, float* dst, int L, int hd) {   // [L
 // streamed operand serves four multiply-adds.
 __global__ __launch_bounds__(kSmallThreads) void k_attn_small_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                                   const float* __restrict__ V, float* __restrict__ O, int heads,
-                                                                  int L, int hd, float scale) {
+                                                                  int L, int hd, float scale, const QkvLayout lay) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ld = pad(hd), ls = L + 1, hq = hd >> 2;
     float *Qs = sm, *Ks = Qs + L * ld, *Vs = Ks + L * ld, *S = Vs + L * ld;
     const int bh = blockIdx.x, b = bh / heads, head = bh - b * heads;
-    const size_t base = (size_t)bh * L * hd;
-    load_rows(Q + base, Qs, L, hd);
-    load_rows(K + base, Ks, L, hd);
-    load_rows(V + base, Vs, L, hd);
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    load_rows(Q + base, Qs, L, hd, lay.rs);
+    load_rows(K + base, Ks, L, hd, lay.rs);
+    load_rows(V + base, Vs, L, hd, lay.rs);
     __syncthreads();
     scores_softmax(Qs, Ks, S, L, hd, scale);
     for (int e = threadIdx.x; e < L * hq; e += kSmallThreads) {
@@ -107,15 +108,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_attn_small_fwd(const float* _
 __global__ __launch_bounds__(kSmallThreads) void k_attn_small_bwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                                   const float* __restrict__ V, const float* __restrict__ dO,
                                                                   float* __restrict__ dQ, float* __restrict__ dK,
-                                                                  float* __restrict__ dV, int heads, int L, int hd, float scale) {
+                                                                  float* __restrict__ dV, int heads, int L, int hd, float scale,
+                                                                  const QkvLayout lay) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, ld = pad(hd), ls = L + 1, hq = hd >> 2;
     float *Qs = sm, *Ks = Qs + L * ld, *Vs = Ks + L * ld, *Gs = Vs + L * ld, *P = Gs + L * ld, *dS = P + L * ls;
     const int bh = blockIdx.x, b = bh / heads, head = bh - b * heads;
-    const size_t base = (size_t)bh * L * hd;
-    load_rows(Q + base, Qs, L, hd);
-    load_rows(K + base, Ks, L, hd);
-    load_rows(V + base, Vs, L, hd);
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    load_rows(Q + base, Qs, L, hd, lay.rs);
+    load_rows(K + base, Ks, L, hd, lay.rs);
+    load_rows(V + base, Vs, L, hd, lay.rs);
     for (int e = tid; e < L * hq; e += kSmallThreads) {   // dO arrives in token order
         const int i = e / hq, dq = e - i * hq;
         *reinterpret_cast<float4*>(Gs + i * ld + 4 * dq) = ld4(dO + ((size_t)b * L + i) * (heads * hd) + head * hd + 4 * dq);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_attn_small_bwd(const float* _
             aq.x = fmaf(s, k.x, aq.x); aq.y = fmaf(s, k.y, aq.y); aq.z = fmaf(s, k.z, aq.z); aq.w = fmaf(s, k.w, aq.w);
             ak.x = fmaf(t, qv.x, ak.x); ak.y = fmaf(t, qv.y, ak.y); ak.z = fmaf(t, qv.z, ak.z); ak.w = fmaf(t, qv.w, ak.w);
         }
-        const size_t o = base + (size_t)r * hd + 4 * dq;
+        const size_t o = base + (size_t)r * lay.rs + 4 * dq;
         *reinterpret_cast<float4*>(dV + o) = av;
         *reinterpret_cast<float4*>(dQ + o) = make_float4(aq.x * scale, aq.y * scale, aq.z * scale, aq.w * scale);
         *reinterpret_cast<float4*>(dK + o) = make_float4(ak.x * scale, ak.y * scale, ak.z * scale, ak.w * scale);
@@ -163,8 +165,8 @@ static size_t small_lds(int L, int hd, bool bwd) {
     return ((size_t)(bwd ? 4 : 3) * L * (hd + 4) + (size_t)(bwd ? 2 : 1) * L * (L + 1)) * sizeof(float);
 }
 
-hipError_t launch_attention_small_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L, int hd,
-                                      hipStream_t stream) {
+static hipError_t small_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L, int hd,
+                            const QkvLayout lay, hipStream_t stream) {
     if (!attention_small_train_supported(B, heads, L, hd)) return hipErrorInvalidValue;
     const size_t lds = small_lds(L, hd, false);
     if (lds > 48 * 1024) {
@@ -172,12 +174,12 @@ hipError_t launch_attention_small_fwd(const float* q, const float* k, const floa
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_attn_small_fwd, dim3(B * heads), dim3(kSmallThreads), lds, stream, q, k, v, out, heads, L, hd,
-                       1.0f / sqrtf((float)hd));
+                       1.0f / sqrtf((float)hd), lay);
     return hipGetLastError();
 }
 
-hipError_t launch_attention_small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
-                                      float* dv, int B, int heads, int L, int hd, hipStream_t stream) {
+static hipError_t small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv,
+                            int B, int heads, int L, int hd, const QkvLayout lay, hipStream_t stream) {
     if (!attention_small_train_supported(B, heads, L, hd)) return hipErrorInvalidValue;
     const size_t lds = small_lds(L, hd, true);
     if (lds > 48 * 1024) {
@@ -185,8 +187,31 @@ hipError_t launch_attention_small_bwd(const float* q, const float* k, const floa
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_attn_small_bwd, dim3(B * heads), dim3(kSmallThreads), lds, stream, q, k, v, dout, dq, dk, dv, heads, L, hd,
-                       1.0f / sqrtf((float)hd));
+                       1.0f / sqrtf((float)hd), lay);
     return hipGetLastError();
+}
+
+hipError_t launch_attention_small_fwd(const float* q, const float* k, const float* v, float* out, int B, int heads, int L, int hd,
+                                      hipStream_t stream) {
+    return small_fwd(q, k, v, out, B, heads, L, hd, QkvLayout{hd, (long long)heads * L * hd, L * hd}, stream);
+}
+
+hipError_t launch_attention_small_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                                      float* dv, int B, int heads, int L, int hd, hipStream_t stream) {
+    return small_bwd(q, k, v, dout, dq, dk, dv, B, heads, L, hd, QkvLayout{hd, (long long)heads * L * hd, L * hd}, stream);
+}
+
+// q, k, v read from, and dq, dk, dv written to, the output layout of a fused QKV projection: qkv, dqkv [B][L][3][heads * hd]
+hipError_t launch_attention_small_qkv_fwd(const float* qkv, float* out, int B, int heads, int L, int hd, hipStream_t stream) {
+    const int C = heads * hd;
+    return small_fwd(qkv, qkv + C, qkv + 2 * C, out, B, heads, L, hd, QkvLayout{3 * C, (long long)L * 3 * C, hd}, stream);
+}
+
+hipError_t launch_attention_small_qkv_bwd(const float* qkv, const float* dout, float* dqkv, int B, int heads, int L, int hd,
+                                          hipStream_t stream) {
+    const int C = heads * hd;
+    return small_bwd(qkv, qkv + C, qkv + 2 * C, dout, dqkv, dqkv + C, dqkv + 2 * C, B, heads, L, hd,
+                     QkvLayout{3 * C, (long long)L * 3 * C, hd}, stream);
 }
 
 }  // namespace danra

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "danra_attention_small_supported": (ctypes.c_int, [ctypes.c_int] * 4),
     "danra_attention_small_fwd": (ctypes.c_int, [_P] * 4 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_small_bwd": (ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 4 + [_P]),
+    "danra_attention_small_qkv_fwd": (ctypes.c_int, [_P] * 2 + [ctypes.c_int] * 4 + [_P]),
+    "danra_attention_small_qkv_bwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_core_qkv_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_core_qkv_bwd": (ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 4 + [_P]),
     "danra_attention_core_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
@@ -354,6 +356,40 @@ class _AttentionCoreSmall(torch.autograd.Function):
         return dqkv
 
 
+class _AttentionCoreSmallQkv(torch.autograd.Function):
+    """The short-sequence core on the fused QKV projection's output used in place (danra_attention_small_qkv_fwd / _bwd):
+    qkv [B, L, 3 * heads * head_dim] contiguous -> tokens [B, L, heads*head_dim]; the gradient comes back in qkv's layout."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, qkv, heads):
+        lib = load_library()
+        qkv = qkv.contiguous()
+        B, L, C3 = qkv.shape
+        hd = C3 // (3 * heads)
+        out = torch.empty((B, L, heads * hd), device=qkv.device, dtype=torch.float32)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_small_qkv_fwd(_ptr(qkv), _ptr(out), B, heads, L, hd, _stream()),
+                   "danra_attention_small_qkv_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        lib = load_library()
+        (qkv,) = ctx.saved_tensors
+        B, L, C3 = qkv.shape
+        heads = ctx.heads
+        dout = _f32(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _check(lib, lib.danra_attention_small_qkv_bwd(_ptr(qkv), _ptr(dout), _ptr(dqkv), B, heads, L, C3 // (3 * heads),
+                                                          _stream()), "danra_attention_small_qkv_bwd")
+        return dqkv, None
+
+
 def attention_small_supported(tokens, n_heads):
     """True when the differentiable self-attention of [B, L, C] `tokens` can run its core in the native library's
     short-sequence kernels: a CUDA tensor (float32; half precision under autocast), at most 64 tokens."""
@@ -471,13 +507,12 @@ def differentiable_self_attention(mha, tokens):
     B, L, C = tokens.shape
     heads = mha.num_heads
     qkv = token_linear(tokens, mha.in_proj_weight, mha.in_proj_bias)
-    if attention_core_supported(tokens, heads):
-        attended = _AttentionCoreHD16Qkv.apply(qkv, heads)  # the projection's [B, L, 3 C] output in place
-        return token_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
-    qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
-    if attention_small_supported(tokens, heads):
-        attended = _AttentionCoreSmall.apply(qkv)
+    if attention_core_supported(tokens, heads):        # (both native cores read the projection's [B, L, 3 C] output in place)
+        attended = _AttentionCoreHD16Qkv.apply(qkv, heads)
+    elif attention_small_supported(tokens, heads):
+        attended = _AttentionCoreSmallQkv.apply(qkv, heads)
     else:
+        qkv = qkv.view(B, L, 3, heads, C // heads).permute(2, 0, 3, 1, 4)  # [3, B, heads, L, head_dim]
         attended = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         attended = attended.permute(0, 2, 1, 3).reshape(B, L, C)
     return token_linear(attended, mha.out_proj.weight, mha.out_proj.bias)

@@ -202,6 +202,11 @@ int danra_attention_small_fwd(const float* q_dev, const float* k_dev, const floa
                               int head_dim, void* stream);
 int danra_attention_small_bwd(const float* q_dev, const float* k_dev, const float* v_dev, const float* dout_dev, float* dq_dev,
                               float* dk_dev, float* dv_dev, int B, int heads, int L, int head_dim, void* stream);
+/* Both on the output of the block's fused QKV projection used in place, qkv_dev, dqkv_dev [B][L][3][heads*head_dim] (see
+ * danra_attention_core_qkv_fwd). */
+int danra_attention_small_qkv_fwd(const float* qkv_dev, float* out_dev, int B, int heads, int L, int head_dim, void* stream);
+int danra_attention_small_qkv_bwd(const float* qkv_dev, const float* dout_dev, float* dqkv_dev, int B, int heads, int L,
+                                  int head_dim, void* stream);
 /* nn.BatchNorm2d in TRAIN mode (the encoder's bn1 and the BasicBlocks' bn1 / bn2 / downsample.1 after model.train(),
  * training_DANRA_conditional.py:517; modules_DANRA_conditional.py:271 and torchvision's BasicBlock.forward): batch
  * statistics per channel over (B, H, W), y = (x - mean) / sqrt(var_biased + eps) * gamma + beta, optionally followed by the

@@ -690,7 +690,7 @@ def native_call_counters(monkeypatch):
              "danra_batchnorm_train_add_relu_fwd", "danra_batchnorm_train_add_relu_bwd", "danra_instancenorm_fwd", "danra_instancenorm_bwd", "danra_linear_wgrad", "danra_conv3x3_train_fwd",
              "danra_conv3x3_train_dgrad", "danra_conv3x3_train_wgrad", "danra_pointwise_train_fwd",
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
-             "danra_tokens_to_nchw_add", "danra_attention_small_fwd", "danra_attention_small_bwd",
+             "danra_tokens_to_nchw_add", "danra_attention_small_qkv_fwd", "danra_attention_small_qkv_bwd",
              "danra_conv3x3_c1_train_fwd", "danra_conv3x3_c1_train_dgrad", "danra_conv3x3_c1_train_wgrad",
              "danra_conv8x8s2_train_fwd", "danra_conv8x8s2_train_dgrad", "danra_conv8x8s2_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
@@ -702,8 +702,8 @@ def native_call_counters(monkeypatch):
 # has stride 2 and goes through the stride-1 kernels) and the four decoder blocks' (the final block's has one output
 # channel and kernels of its own), each in three directions; the cores of the five attention blocks at 128 channels and more
 EXPECTED_NATIVE_CALLS = {"danra_conv3x3_c1_train_fwd": 1, "danra_conv3x3_c1_train_dgrad": 1, "danra_conv3x3_c1_train_wgrad": 1,
-                         "danra_attention_core_qkv_fwd": 4, "danra_attention_core_qkv_bwd": 4, "danra_attention_small_fwd": 5,
-                         "danra_attention_small_bwd": 5, "danra_batchnorm_train_fwd": 12,
+                         "danra_attention_core_qkv_fwd": 4, "danra_attention_core_qkv_bwd": 4, "danra_attention_small_qkv_fwd": 5,
+                         "danra_attention_small_qkv_bwd": 5, "danra_batchnorm_train_fwd": 12,
                          "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
                          "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 20, "danra_conv3x3_train_dgrad": 20,
@@ -910,6 +910,15 @@ def test_short_sequence_core_forward_and_backward_match_float64(B, heads, L, hd,
     close(dv.cpu(), want_dv, 1e-5, "dv")
     close(dq.cpu(), want_dq, 1e-5, "dq")
     close(dk.cpu(), want_dk, 1e-5, "dk")
+    # the same kernels on the layout of the fused QKV projection, [B][L][3][heads*hd], read and written in place: bit for bit
+    qkv = torch.stack([t.permute(0, 2, 1, 3).reshape(B, L, heads * hd) for t in (q, k, v)], dim=2).to(DEV).contiguous()
+    out2, dqkv = torch.empty_like(out), torch.full_like(qkv, float("nan"))
+    _check(lib, lib.danra_attention_small_qkv_fwd(_ptr(qkv), _ptr(out2), B, heads, L, hd, _stream()), "qkv fwd")
+    _check(lib, lib.danra_attention_small_qkv_bwd(_ptr(qkv), _ptr(dd), _ptr(dqkv), B, heads, L, hd, _stream()), "qkv bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    for i, want in enumerate((dq, dk, dv)):
+        assert torch.equal(dqkv[:, :, i].reshape(B, L, heads, hd).permute(0, 2, 1, 3), want), "qkv"[i]
 
 
 def test_short_sequence_core_refuses_other_shapes_and_runs_in_the_attention_block():
@@ -924,12 +933,12 @@ def test_short_sequence_core_refuses_other_shapes_and_runs_in_the_attention_bloc
     mha = torch.nn.MultiheadAttention(128, 4, batch_first=True).to(DEV)
     tokens = torch.randn(6, 64, 128, device=DEV, requires_grad=True)
     calls = []
-    real = hip_engine._AttentionCoreSmall.apply
+    real = hip_engine._AttentionCoreSmallQkv.apply
     try:
-        hip_engine._AttentionCoreSmall.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        hip_engine._AttentionCoreSmallQkv.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
         got = hip_engine.differentiable_self_attention(mha, tokens)
     finally:
-        hip_engine._AttentionCoreSmall.apply = real
+        hip_engine._AttentionCoreSmallQkv.apply = real
     assert calls, "the native core did not run"
     g = torch.randn_like(got)
     got.backward(g)
