@@ -1608,6 +1608,44 @@ int danra_conv3x3_c1_train_wgrad(const float* x, const float* dy, float* dw, int
     return DANRA_OK;
 }
 
+int danra_conv3x3s2_train_supported(int B, int Cin, int Cout, int H, int W) {
+    return conv3x3s2_train_supported(B, Cin, Cout, H, W) ? 1 : 0;
+}
+
+size_t danra_conv3x3s2_train_workspace(int B, int Cin, int Cout, int H, int W) {
+    return conv3x3s2_train_supported(B, Cin, Cout, H, W) ? conv3x3s2_train_workspace_floats(B, Cin, Cout, H, W) * sizeof(float) : 0;
+}
+
+static int conv3s2_train_check(const void* a, const void* b, const void* c, const void* ws, int B, int Cin, int Cout, int H,
+                               int W) {
+    if (!a || !b || !c || !ws) return fail(DANRA_EINVAL, "null argument");
+    if (!conv3x3s2_train_supported(B, Cin, Cout, H, W))
+        return fail(DANRA_EINVAL, "B=%d Cin=%d Cout=%d H=%d W=%d: not a shape the 3x3 stride-2 training kernels take "
+                    "(danra_conv3x3s2_train_supported)", B, Cin, Cout, H, W);
+    return DANRA_OK;
+}
+
+int danra_conv3x3s2_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, void* workspace,
+                              void* stream) {
+    RC_TRY(conv3s2_train_check(x, w, y, workspace, B, Cin, Cout, H, W));
+    HIP_TRY(launch_conv3x3s2_train_fwd(x, w, y, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv3x3s2_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W,
+                                void* workspace, void* stream) {
+    RC_TRY(conv3s2_train_check(dy, w, dx, workspace, B, Cin, Cout, H, W));
+    HIP_TRY(launch_conv3x3s2_train_dgrad(dy, w, dx, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
+int danra_conv3x3s2_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                void* workspace, void* stream) {
+    RC_TRY(conv3s2_train_check(x, dy, dw, workspace, B, Cin, Cout, H, W));
+    HIP_TRY(launch_conv3x3s2_train_wgrad(x, dy, dw, B, Cin, Cout, H, W, static_cast<float*>(workspace), (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_conv8x8s2_train_supported(int B, int Cin, int Cout, int H, int W) {
     return conv8s2_train_supported(B, Cin, Cout, H, W) ? 1 : 0;
 }

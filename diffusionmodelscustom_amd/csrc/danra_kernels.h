@@ -135,6 +135,16 @@ struct QkvLayout {
     long long img;
     int hs;
 };
+// The 3x3 stride-2 padding-1 convolutions in a training step, NCHW fp32 (kernels_conv3s2_train.hip): x, dx [B][Cin][H][W];
+// w, dw [Cout][Cin][3][3]; y, dy [B][Cout][H/2][W/2]; workspace: conv3x3s2_train_workspace_floats floats.
+bool conv3x3s2_train_supported(int B, int Cin, int Cout, int H, int W);
+size_t conv3x3s2_train_workspace_floats(int B, int Cin, int Cout, int H, int W);
+hipError_t launch_conv3x3s2_train_fwd(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W,
+                                      float* workspace, hipStream_t stream);
+hipError_t launch_conv3x3s2_train_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W,
+                                        float* workspace, hipStream_t stream);
+hipError_t launch_conv3x3s2_train_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                        float* workspace, hipStream_t stream);
 // The 8x8 stride-2 padding-3 convolutions of the stem in a training step, NCHW fp32 (kernels_conv8_train.hip): x, dx
 // [B][Cin][H][W]; w, dw [Cout][Cin][8][8]; y, dy [B][Cout][H/2][W/2]; workspace: conv8s2_train_workspace_floats floats.
 bool conv8s2_train_supported(int B, int Cin, int Cout, int H, int W);

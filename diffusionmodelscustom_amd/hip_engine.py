@@ -64,6 +64,11 @@ _SIGNATURES = {
     "danra_attention_core_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_attention_core_presplit_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_set_fp32_products": (ctypes.c_int, [ctypes.c_int]),
+    "danra_conv3x3s2_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "danra_conv3x3s2_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "danra_conv3x3s2_train_fwd": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
+    "danra_conv3x3s2_train_dgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
+    "danra_conv3x3s2_train_wgrad": (ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     "danra_conv8x8s2_train_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "danra_conv8x8s2_train_dgrad_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "danra_conv8x8s2_train_workspace": (ctypes.c_size_t, [ctypes.c_int] * 5),
@@ -768,6 +773,49 @@ class _Conv3x3C1Train(torch.autograd.Function):
         return dx, dw
 
 
+class _Conv3x3S2Train(torch.autograd.Function):
+    """torch.nn.functional.conv2d(x, weight, None, stride=2, padding=1) for a 3x3 kernel on a contiguous NCHW fp32 CUDA tensor
+    with even sides: forward, data gradient and weight gradient in libdanra_hip.so (danra_conv3x3s2_train_fwd / _dgrad /
+    _wgrad), tensors and weight used where they lie."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, x, weight):
+        lib = load_library()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B, Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(lib.danra_conv3x3s2_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _check(lib, lib.danra_conv3x3s2_train_fwd(_ptr(x), _ptr(weight), _ptr(y), B, Cin, Cout, H, W, _ptr(ws), _stream()),
+                   "danra_conv3x3s2_train_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        lib = load_library()
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = _f32(dy, "dy")
+        ws = torch.empty(max(lib.danra_conv3x3s2_train_workspace(B, Cin, Cout, H, W) // 4, 1), device=x.device, dtype=torch.float32)
+        dx = dw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(lib, lib.danra_conv3x3s2_train_dgrad(_ptr(dy), _ptr(weight), _ptr(dx), B, Cin, Cout, H, W, _ptr(ws),
+                                                            _stream()), "danra_conv3x3s2_train_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                _check(lib, lib.danra_conv3x3s2_train_wgrad(_ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
+                                                            _stream()), "danra_conv3x3s2_train_wgrad")
+        return dx, dw
+
+
 class _Conv8x8S2Train(torch.autograd.Function):
     """torch.nn.functional.conv2d(x, weight, None, stride=2, padding=3) for an 8x8 kernel (the two stem convolutions of the
     encoder) on a contiguous NCHW fp32 CUDA tensor: forward, data gradient and weight gradient in libdanra_hip.so
@@ -982,16 +1030,18 @@ def conv2d(conv, x):
         if conv.out_channels == 1 and load_library().danra_conv3x3_c1_train_supported(B, Cin, H, W):   # the network's last convolution
             y = _Conv3x3C1Train.apply(x, conv.weight)
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
-    # 3x3, stride 2, padding 1 on even sides (the first convolution of a down-sampling BasicBlock): the stride-1 kernels
-    # evaluated everywhere, every second row and column kept - four times the products of three small layers (3 % of a
-    # step's), in exchange for forward, data gradient and weight gradient in the library; autograd scatters dy back into
-    # the full map
+    # 3x3, stride 2, padding 1 on even sides (the first convolution of a down-sampling BasicBlock): kernels of its own
+    # (danra_conv3x3s2_train_*); a map they do not take (sides that are not powers of two) goes through the stride-1 kernels
+    # evaluated everywhere with every second row and column kept, and autograd scatters dy back into the full map
     if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
             and type(conv) is torch.nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and _native_dtype(x)
             and conv.weight.dtype == torch.float32 and (x.requires_grad or conv.weight.requires_grad)
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
         B, Cin, H, W = x.shape
+        if load_library().danra_conv3x3s2_train_supported(B, Cin, conv.out_channels, H, W):
+            y = _Conv3x3S2Train.apply(x, conv.weight)
+            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)[:, :, ::2, ::2]
             return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)

@@ -288,6 +288,21 @@ int danra_conv3x3_c1_train_fwd(const float* x_dev, const float* w_dev, float* y_
 int danra_conv3x3_c1_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int H, int W, void* stream);
 int danra_conv3x3_c1_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int H, int W,
                                  void* workspace, void* stream);
+/* The 3x3, stride-2, padding-1 convolutions of the training step (conv1 of the first BasicBlock of layer2 / layer3 / layer4,
+ * modules_DANRA_conditional.py:154 through torchvision's _make_layer) on contiguous NCHW fp32 tensors with the
+ * [Cout][Cin][3][3] weight as torch holds it: x, dx [B][Cin][H][W]; y, dy [B][Cout][H/2][W/2].  Shapes
+ * (danra_conv3x3s2_train_supported): H, W even, W/2 a power of two in 2..64, (H/2)(W/2) a divisor of 64 or a multiple of it by
+ * whole rows, Cin a multiple of 32, Cout a multiple of 64.  workspace: danra_conv3x3s2_train_workspace(...) bytes of device
+ * memory (slabs of the sums that run over workgroups, added in a fixed order: bit-reproducible). */
+int danra_conv3x3s2_train_supported(int B, int Cin, int Cout, int H, int W);
+size_t danra_conv3x3s2_train_workspace(int B, int Cin, int Cout, int H, int W);
+int danra_conv3x3s2_train_fwd(const float* x_dev, const float* w_dev, float* y_dev, int B, int Cin, int Cout, int H, int W,
+                              void* workspace_dev, void* stream);
+int danra_conv3x3s2_train_dgrad(const float* dy_dev, const float* w_dev, float* dx_dev, int B, int Cin, int Cout, int H, int W,
+                                void* workspace_dev, void* stream);
+int danra_conv3x3s2_train_wgrad(const float* x_dev, const float* dy_dev, float* dw_dev, int B, int Cin, int Cout, int H, int W,
+                                void* workspace_dev, void* stream);
+
 /* The two stem convolutions of the encoder in a training step: 8x8, stride 2, padding 3, no bias
  * (modules_DANRA_conditional.py:186-191: conv1 on the 1-4 input planes, conv2 64 -> 64), on contiguous NCHW fp32 tensors with
  * the [Cout][Cin][8][8] weight as torch holds it: x, dx [B][Cin][H][W]; y, dy [B][Cout][H/2][W/2].  Shapes

@@ -692,7 +692,8 @@ def native_call_counters(monkeypatch):
              "danra_pointwise_train_dgrad", "danra_pointwise_train_wgrad", "danra_ln_tokens_fwd", "danra_ln_tokens_bwd",
              "danra_tokens_to_nchw_add", "danra_attention_small_qkv_fwd", "danra_attention_small_qkv_bwd",
              "danra_conv3x3_c1_train_fwd", "danra_conv3x3_c1_train_dgrad", "danra_conv3x3_c1_train_wgrad",
-             "danra_conv8x8s2_train_fwd", "danra_conv8x8s2_train_dgrad", "danra_conv8x8s2_train_wgrad")
+             "danra_conv8x8s2_train_fwd", "danra_conv8x8s2_train_dgrad", "danra_conv8x8s2_train_wgrad",
+             "danra_conv3x3s2_train_fwd", "danra_conv3x3s2_train_dgrad", "danra_conv3x3s2_train_wgrad")
     return {n: count_calls(monkeypatch, n) for n in names}
 
 
@@ -706,8 +707,9 @@ EXPECTED_NATIVE_CALLS = {"danra_conv3x3_c1_train_fwd": 1, "danra_conv3x3_c1_trai
                          "danra_attention_small_qkv_bwd": 5, "danra_batchnorm_train_fwd": 12,
                          "danra_batchnorm_train_bwd": 12, "danra_batchnorm_train_add_relu_fwd": 8,
                          "danra_batchnorm_train_add_relu_bwd": 8, "danra_instancenorm_fwd": 9, "danra_instancenorm_bwd": 9,
-                         "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 20, "danra_conv3x3_train_dgrad": 20,
-                         "danra_conv3x3_train_wgrad": 20,
+                         "danra_linear_wgrad": 8, "danra_conv3x3_train_fwd": 17, "danra_conv3x3_train_dgrad": 17,
+                         "danra_conv3x3_train_wgrad": 17,
+                         "danra_conv3x3s2_train_fwd": 3, "danra_conv3x3s2_train_dgrad": 3, "danra_conv3x3s2_train_wgrad": 3,
                          # the two 8x8 stride-2 stem convolutions (conv1's input planes ask for no gradient)
                          "danra_conv8x8s2_train_fwd": 2, "danra_conv8x8s2_train_dgrad": 1, "danra_conv8x8s2_train_wgrad": 2,
                          # the three 1x1 stride-2 shortcut convolutions and the five transposed convolutions
