@@ -1686,6 +1686,14 @@ int danra_conv8x8s2_train_wgrad(const float* x, const float* dy, float* dw, int 
     return DANRA_OK;
 }
 
+int danra_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
+    if (!x || !out) return fail(DANRA_EINVAL, "null argument");
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * C * HW >= (1LL << 31))
+        return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", B, C, HW);
+    HIP_TRY(launch_channel_sum(x, out, B, C, HW, (hipStream_t)stream));
+    return DANRA_OK;
+}
+
 int danra_ln_tokens_supported(int B, int C, int L) { return ln_tokens_supported(B, C, L) ? 1 : 0; }
 
 size_t danra_ln_tokens_workspace(int B, int C, int L) { return ln_tokens_workspace_floats(B, C, L) * sizeof(float); }

@@ -223,6 +223,39 @@ hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* 
     return hipGetLastError();
 }
 
+// out[c] = sum over images and positions of x[b][c][.] (the gradient of a convolution's bias): one workgroup per channel,
+// partial sums per thread in a fixed order, then the block's tree: the same bits on every call.
+__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int hw4 = HW / 4, per = B * hw4;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains: the loads of four iterations in flight
+    auto at = [&](int i) -> float4 {
+        const int b = i / hw4, r = i - b * hw4;
+        return *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + 4 * (size_t)r);
+    };
+    int i = tid;
+    for (; i + 768 < per; i += 1024) {
+        const float4 a = at(i), b4 = at(i + 256), c4 = at(i + 512), d4 = at(i + 768);
+        s0 += (a.x + a.y) + (a.z + a.w);
+        s1 += (b4.x + b4.y) + (b4.z + b4.w);
+        s2 += (c4.x + c4.y) + (c4.z + c4.w);
+        s3 += (d4.x + d4.y) + (d4.z + d4.w);
+    }
+    for (; i < per; i += 256) {
+        const float4 a = at(i);
+        s0 += (a.x + a.y) + (a.z + a.w);
+    }
+    const float total = block_sum256((s0 + s1) + (s2 + s3), red);
+    if (tid == 0) out[c] = total;
+}
+
+hipError_t launch_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_channel_sum, dim3(C), dim3(256), 0, stream, x, out, B, C, HW);
+    return hipGetLastError();
+}
+
 hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
                                const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
                                hipStream_t stream, float* dres) {

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "danra_batchnorm_train_add_relu_fwd": (ctypes.c_int, [_P] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _P, _P]),
     "danra_batchnorm_train_add_relu_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int] * 3 + [_P]),
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
+    "danra_channel_sum": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -946,6 +947,40 @@ def tokens_residual_nchw(tokens, x):
     return _TokensResidualNCHW.apply(tokens, x)
 
 
+def channel_sum(t):
+    """t.sum((0, 2, 3)) of a 4-D fp32 CUDA tensor through the native kernel (contiguous NCHW, H*W a multiple of 4), torch's
+    reduction otherwise."""
+    if t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous() and (t.shape[2] * t.shape[3]) % 4 == 0 \
+            and 0 < t.numel() < (1 << 31):
+        lib = load_library()
+        out = torch.empty(t.shape[1], device=t.device, dtype=torch.float32)
+        with torch.cuda.device(t.device):
+            _check(lib, lib.danra_channel_sum(_ptr(t), _ptr(out), t.shape[0], t.shape[1], t.shape[2] * t.shape[3], _stream()),
+                   "danra_channel_sum")
+        return out
+    return t.sum((0, 2, 3))
+
+
+class _AddChannelBias(torch.autograd.Function):
+    """y + bias.view(1, -1, 1, 1) for a convolution's output: torch's add forward; backward the gradient itself for y and
+    its per-channel sum (danra_channel_sum) for the bias."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, y, bias):
+        return y + bias.view(1, -1, 1, 1)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dy):
+        return (dy if ctx.needs_input_grad[0] else None,
+                channel_sum(dy) if ctx.needs_input_grad[1] else None)
+
+
+def _with_bias(y, bias):
+    return y if bias is None else _AddChannelBias.apply(y, bias)
+
+
 PW_CONV1X1_S2, PW_CONVT2X2 = 0, 1
 
 
@@ -992,7 +1027,7 @@ class _PointwiseTrain(torch.autograd.Function):
                 _check(lib, lib.danra_pointwise_train_wgrad(kind, _ptr(x), _ptr(dy), _ptr(dw), B, Cin, Cout, H, W, _ptr(ws),
                                                             _stream()), "danra_pointwise_train_wgrad")
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = dy.sum((0, 2, 3))
+                db = channel_sum(dy)
         return dx, dw, db, None
 
 
@@ -1026,10 +1061,10 @@ def conv2d(conv, x):
         B, Cin, H, W = x.shape
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)
-            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+            return _with_bias(y, conv.bias)
         if conv.out_channels == 1 and load_library().danra_conv3x3_c1_train_supported(B, Cin, H, W):   # the network's last convolution
             y = _Conv3x3C1Train.apply(x, conv.weight)
-            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+            return _with_bias(y, conv.bias)
     # 3x3, stride 2, padding 1 on even sides (the first convolution of a down-sampling BasicBlock): kernels of its own
     # (danra_conv3x3s2_train_*); a map they do not take (sides that are not powers of two) goes through the stride-1 kernels
     # evaluated everywhere with every second row and column kept, and autograd scatters dy back into the full map
@@ -1041,10 +1076,10 @@ def conv2d(conv, x):
         B, Cin, H, W = x.shape
         if load_library().danra_conv3x3s2_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3S2Train.apply(x, conv.weight)
-            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+            return _with_bias(y, conv.bias)
         if load_library().danra_conv3x3_train_supported(B, Cin, conv.out_channels, H, W):
             y = _Conv3x3Train.apply(x, conv.weight)[:, :, ::2, ::2]
-            return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+            return _with_bias(y, conv.bias)
     # 8x8, stride 2, padding 3, no bias: the two stem convolutions (an input that asks for a gradient needs the data-gradient
     # kernel, which exists for 32-channel multiples only)
     if (native_training_kernels and native_training_convolutions and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4

@@ -234,6 +234,11 @@ int danra_batchnorm_train_add_relu_bwd(const float* x_dev, const float* dy_dev, 
                                        const float* save_mean_dev, const float* save_rstd_dev, float* dx_dev, float* dres_dev,
                                        float* dgamma_dev, float* dbeta_dev, int B, int C, int HW, void* stream);
 
+/* out[c] = sum over b, h, w of x[b][c][h][w] on contiguous NCHW fp32 (HW a multiple of 4): the bias gradient of the decoder's
+ * nn.Conv2d / nn.ConvTranspose2d layers (modules_DANRA_conditional.py:407-417; autograd's dy.sum((0, 2, 3))), summed in a fixed
+ * order. */
+int danra_channel_sum(const float* x_dev, float* out_dev, int B, int C, int HW, void* stream);
+
 /* nn.InstanceNorm2d(affine=False) as the decoder blocks use it (modules_DANRA_conditional.py:412,419) on NCHW fp32 with
  * its autograd backward, for the training step: `planes` = B*C planes of HW contiguous values each (HW a multiple of 4);
  * y = (x - mean) / sqrt(var_biased + eps) per plane; save_mean / save_rstd: [planes], kept for the backward pass

@@ -406,3 +406,18 @@ def test_stem_convolution_refusals():
     out = hip_engine.conv2d(conv, xr)
     out.sum().backward()
     assert xr.grad is not None and torch.isfinite(xr.grad).all()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(32, 64, 64, 64), (3, 512, 2, 2), (5, 1, 16, 16), (2, 96, 6, 10)])
+def test_channel_sum_matches_float64_and_is_reproducible(B, C, H, W):
+    """danra_channel_sum (the bias gradient of the decoder's convolutions, autograd's dy.sum((0, 2, 3))) against float64;
+    two calls agree bit for bit; a layout the kernel does not take goes through torch's reduction."""
+    g = torch.Generator().manual_seed(C + H)
+    t = (torch.randn(B, C, H, W, generator=g) + 0.3).to(DEV)
+    got = hip_engine.channel_sum(t)
+    want = t.double().cpu().sum((0, 2, 3))
+    err = (got.double().cpu() - want).abs().max().item()
+    assert err <= 1e-6 * t.double().abs().sum((0, 2, 3)).max().item(), err
+    assert torch.equal(got, hip_engine.channel_sum(t))
+    odd = t[:, :, :, : W - 1]                      # not contiguous: torch's reduction
+    assert torch.allclose(hip_engine.channel_sum(odd).cpu(), odd.cpu().sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
