@@ -218,6 +218,7 @@ hipError_t launch_attention_hd16(const float* q, const float* k, const float* v,
 // on != 0: every later launch_attention_hd16 multiplies with fp32 matrix instructions only (v_mfma_f32_16x16x4_f32)
 // instead of the split-operand fp16 products.  Process-wide; for numerical cross-checks.
 void set_attention_hd16_fp32_products(int on);
+int attention_hd16_fp32_products();
 // Gradients of that forward: dout tokens [B][L][heads*16] -> dq, dk, dv [B*heads][L][16]; delta: [B*heads][L] scratch
 // (receives sum_d dout*out per query).  Two kernels, no atomics.
 hipError_t launch_attention_hd16_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,

@@ -1565,6 +1565,7 @@ hipError_t launch_attention_hd16_pre(const float* q, const float* ks, const floa
 
 static int g_hd16_fp32_products = 0;
 void set_attention_hd16_fp32_products(int on) { g_hd16_fp32_products = on ? 1 : 0; }
+int attention_hd16_fp32_products() { return g_hd16_fp32_products; }
 
 hipError_t launch_attention_hd16(const float* q, const float* k, const float* v, float* out, float* lse2, int B,
                                  int heads, int L, hipStream_t stream) {

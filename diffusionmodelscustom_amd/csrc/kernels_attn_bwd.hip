@@ -17,6 +17,7 @@
 // fp32 matrix cores (v_mfma_f32_16x16x4_f32) throughout: operand A lane (i, k-slot), operand B lane (j, k-slot),
 // result lane (j, g) holds rows 4g .. 4g+3 of column j.
 #include "danra_kernels.h"
+#include "split_f16.h"
 
 namespace danra {
 
@@ -131,6 +132,228 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq(const float* __restri
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float4 o = make_float4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+        *reinterpret_cast<float4*>(dQ + base + (size_t)(q0 + t * 16 + lq) * RS + 4 * g) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same gradient with the three products on the fp16 matrix cores, operands split in two fp16 halves as the forward
+// kernel splits them (x = h + 2^-11 l, h rounded towards zero; 22 significant bits, the l l term dropped):
+//   S^T  = [Kh | Kl] [Qh | 2^-11 Qh]^T + [Kh | Kl] [2^-11 Ql | 0]^T                 two 32-deep instructions per 16 keys
+//   dP^T = [Vh | Vl] [Gh | 2^-11 Gh]^T + [Vh | Vl] [2^-11 Gl | 0]^T,  G = 2^-e dO    (e: so that max |G| of the wave's 16
+//          queries lies in [8, 16): gradients are small numbers, and fp16 keeps 22 bits only above 2^-14)
+//   dQ^T += Kh^T dSh + Kh^T dSl + 2^-11 Kl^T dSh,  dS = P o (dP - D) split as hi + lo   three instructions per 32 keys
+// A tile is multiplied this way when every |K|, |V| staged for it is below 2^15, the wave's own q and dO are finite and
+// in range, and 256 max|V| + max|2^-e D| < 2^15 (then no dS leaves the fp16 range); otherwise - per wave and tile - with
+// the fp32 instructions of k_flash_hd16_bwd_dq from the fp32 copy of the tile.  K arrives in LDS three times: rows in
+// fp32, rows as halves [h4 | l4] x 4, and as the A fragments of the third product ([hi, lo][32-key half][d][g][slot],
+// slot 4j + r <-> key 16j + 4g + r: the order in which a lane holds its dS values); V twice.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void k_flash_hd16_bwd_dq_h(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, const float* __restrict__ O,
+                                                             const float* __restrict__ dO, const float* __restrict__ LSE2,
+                                                             float* __restrict__ dQ, float* __restrict__ Dout, int L,
+                                                             int heads, int n_bh, float scale, const QkvLayout lay) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) float Vs[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[2][BT * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[2][BT * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Kt[2][2][2][16 * 4 * 8];
+    __shared__ int slow_s[2][4];      // per staging wave: a value of its 16 keys leaves the range of the halves
+    __shared__ float vmax_s[2][4];    // per staging wave: max |V| of its 16 keys
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bh, qblk;
+    decode_block(blockIdx.x, L / (4 * QT * 16), n_bh, bh, qblk);
+    const int q0 = qblk * (4 * QT * 16) + wave * (QT * 16);
+    const int lq = lane & 15, g = lane >> 4;
+    const int b = bh / heads, head = bh - b * heads, C = heads * 16;
+    const float scale_log2e = scale * 1.4426950408889634f;
+    const int RS = lay.rs;
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    const float* Qb = Q + base;
+    const float* Kb = K + base;
+    const float* Vb = V + base;
+
+    // resident operands of the wave's queries: lane (q, g) holds columns 4g .. 4g+3 of row q, in fp32 and as halves
+    float4 qf[QT], dof[QT];
+    f16x8 qb1[QT], qb2[QT], gb1[QT], gb2[QT];
+    f32x4 neglse[QT], negd[QT], dq[QT], dq2[QT];
+    float unscale[QT];
+    bool bounded = true;
+    float dmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0 + t * 16 + lq;
+        qf[t] = *reinterpret_cast<const float4*>(Qb + (size_t)q * RS + 4 * g);
+        qf[t].x *= scale_log2e; qf[t].y *= scale_log2e; qf[t].z *= scale_log2e; qf[t].w *= scale_log2e;
+        const size_t tok = ((size_t)b * L + q) * C + head * 16 + 4 * g;
+        dof[t] = *reinterpret_cast<const float4*>(dO + tok);
+        const float4 of = *reinterpret_cast<const float4*>(O + tok);
+        float d = dof[t].x * of.x + dof[t].y * of.y + dof[t].z * of.z + dof[t].w * of.w;
+        d += __shfl_xor(d, 16);
+        d += __shfl_xor(d, 32);
+        if (g == 0) Dout[(size_t)bh * L + q] = d;
+        // 2^-e: brings the largest |dO| of these 16 queries into [8, 16) (1 where they are all zero or not finite)
+        const float m = wave_max(fmaxf(fmaxf(fabsf(dof[t].x), fabsf(dof[t].y)), fmaxf(fabsf(dof[t].z), fabsf(dof[t].w))));
+        const int ex = (int)((__float_as_uint(m) >> 23) & 0xff);   // biased exponent of the largest |dO|
+        const bool usable = ex >= 5 && ex <= 250;
+        const float sc = usable ? __uint_as_float((unsigned)(257 - ex) << 23) : 1.0f;     // 2^(3 - (ex - 127))
+        unscale[t] = usable ? __uint_as_float((unsigned)(ex - 3) << 23) : 1.0f;          // 2^((ex - 127) - 3)
+        bounded = bounded && (usable || m == 0.f);   // (not finite, or too small / large to rescale: fp32 instructions)
+        dof[t].x *= sc; dof[t].y *= sc; dof[t].z *= sc; dof[t].w *= sc;
+        d *= sc;
+        dmax = fmaxf(dmax, fabsf(d));
+        const float l2 = LSE2[(size_t)bh * L + q];
+        neglse[t] = f32x4{-l2, -l2, -l2, -l2};
+        negd[t] = f32x4{-d, -d, -d, -d};
+        dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dq2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float qq[4] = {qf[t].x, qf[t].y, qf[t].z, qf[t].w}, gg[4] = {dof[t].x, dof[t].y, dof[t].z, dof[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 qh = (_Float16)qq[i], gh = (_Float16)gg[i];
+            qb1[t][i] = qh;
+            qb1[t][4 + i] = (_Float16)((float)qh * 0.00048828125f);
+            qb2[t][i] = (_Float16)(qq[i] - (float)qh);
+            qb2[t][4 + i] = (_Float16)0.f;
+            gb1[t][i] = gh;
+            gb1[t][4 + i] = (_Float16)((float)gh * 0.00048828125f);
+            gb2[t][i] = (_Float16)(gg[i] - (float)gh);
+            gb2[t][4 + i] = (_Float16)0.f;
+            bounded = bounded && (fabsf(qq[i]) < 32768.f);
+        }
+    }
+    dmax = wave_max(dmax);
+    const bool wave_slow = __any(!bounded || !(dmax < 3.0e38f)) != 0;
+
+    // staging: K and V rows (one float4 each per thread) and, for the A fragments of the third product, one column vd of
+    // the four keys that are neighbours in a lane's slot order
+    const int srow = tid >> 2, sc4 = (tid & 3) * 4;
+    const int vd = lane >> 2, vg = lane & 3, vj = wave & 1, vhalf = wave >> 1;
+    const int vkey = 32 * vhalf + 16 * vj + 4 * vg;
+    float4 kreg, vreg, ktreg;
+    auto load_kv = [&](int tile) {
+        kreg = *reinterpret_cast<const float4*>(Kb + (size_t)(tile * BT + srow) * RS + sc4);
+        vreg = *reinterpret_cast<const float4*>(Vb + (size_t)(tile * BT + srow) * RS + sc4);
+        const float* kp = Kb + (size_t)(tile * BT + vkey) * RS + vd;
+        ktreg = make_float4(kp[0], kp[RS], kp[2 * RS], kp[3 * RS]);
+    };
+    auto stage = [&](int buf) {
+        *reinterpret_cast<float4*>(&Ks[buf][srow * BROW + sc4]) = kreg;
+        *reinterpret_cast<float4*>(&Vs[buf][srow * BROW + sc4]) = vreg;
+        unsigned h[2], l[2];
+        split_scaled_pair_f16(kreg.x, kreg.y, h[0], l[0]);
+        split_scaled_pair_f16(kreg.z, kreg.w, h[1], l[1]);
+        *reinterpret_cast<u32x4*>(&Kh[buf][srow * 32 + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
+        split_scaled_pair_f16(vreg.x, vreg.y, h[0], l[0]);
+        split_scaled_pair_f16(vreg.z, vreg.w, h[1], l[1]);
+        *reinterpret_cast<u32x4*>(&Vh[buf][srow * 32 + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
+        split_scaled_pair_f16(ktreg.x, ktreg.y, h[0], l[0]);
+        split_scaled_pair_f16(ktreg.z, ktreg.w, h[1], l[1]);
+        const int at = (vd * 4 + vg) * 8 + 4 * vj;
+        *reinterpret_cast<u32x2*>(&Kt[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(&Kt[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
+        // (a wave stages 16 keys x 16 columns of the row forms, and the same 16 keys of the column form)
+        const float kmax = fmaxf(fmaxf(fabsf(kreg.x), fabsf(kreg.y)), fmaxf(fabsf(kreg.z), fabsf(kreg.w)));
+        const float vmax = fmaxf(fmaxf(fabsf(vreg.x), fabsf(vreg.y)), fmaxf(fabsf(vreg.z), fabsf(vreg.w)));
+        const bool out = !(kmax < 32768.f) || !(vmax < 32768.f);
+        const int any_out = __any(out);
+        const float wmax = wave_max(out ? 0.f : vmax);
+        if (lane == 0) {
+            slow_s[buf][wave] = any_out ? 1 : 0;
+            vmax_s[buf][wave] = wmax;
+        }
+    };
+    load_kv(0);
+    stage(0);
+    __syncthreads();
+
+    const int ntiles = L / BT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        const int flagged = slow_s[buf][0] | slow_s[buf][1] | slow_s[buf][2] | slow_s[buf][3];
+        const float vtile = fmaxf(fmaxf(vmax_s[buf][0], vmax_s[buf][1]), fmaxf(vmax_s[buf][2], vmax_s[buf][3]));
+        load_kv(min(kt + 1, ntiles - 1));   // unconditional prefetch (the last tile re-reads itself)
+        const float vt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vtile)));
+        const bool fast = !wave_slow && __builtin_amdgcn_readfirstlane(flagged) == 0 && (256.f * vt + dmax < 32768.f);
+        if (fast) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 s[QT][2], dp[QT][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f16x8 ka = *reinterpret_cast<const f16x8*>(&Kh[buf][((2 * hf + j) * 16 + lq) * 32 + 8 * g]);
+                    const f16x8 va = *reinterpret_cast<const f16x8*>(&Vh[buf][((2 * hf + j) * 16 + lq) * 32 + 8 * g]);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb1[t], neglse[t], 0, 0, 0);
+                        s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb2[t], a, 0, 0, 0);
+                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, gb1[t], negd[t], 0, 0, 0);
+                        dp[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, gb2[t], c, 0, 0, 0);
+                    }
+                }
+                const f16x8 kthi = *reinterpret_cast<const f16x8*>(&Kt[buf][0][hf][(lq * 4 + g) * 8]);
+                const f16x8 ktlo = *reinterpret_cast<const f16x8*>(&Kt[buf][1][hf][(lq * 4 + g) * 8]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    u32x4 sh, sl;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float ds[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[t][j][r]) * dp[t][j][r];
+                        unsigned h0, l0, h1, l1;
+                        split_pair_f16(ds[0], ds[1], h0, l0);
+                        split_pair_f16(ds[2], ds[3], h1, l1);
+                        sh[2 * j] = h0; sh[2 * j + 1] = h1;
+                        sl[2 * j] = l0; sl[2 * j + 1] = l1;
+                    }
+                    const f16x8 dsh = __builtin_bit_cast(f16x8, sh), dsl = __builtin_bit_cast(f16x8, sl);
+                    dq2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktlo, dsh, dq2[t], 0, 0, 0);
+                    dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kthi, dsl, dq[t], 0, 0, 0);
+                    dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kthi, dsh, dq[t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // 16 keys at a time, fp32 instructions (dO and D in the scaled form here too)
+                const float4 kf = *reinterpret_cast<const float4*>(&Ks[buf][(j * 16 + lq) * BROW + 4 * g]);
+                const float4 vf = *reinterpret_cast<const float4*>(&Vs[buf][(j * 16 + lq) * BROW + 4 * g]);
+                float kt4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kt4[r] = Ks[buf][(j * 16 + 4 * g + r) * BROW + lq];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 s = neglse[t], dp = negd[t];
+                    MFMA4(s, kf, qf[t]);
+                    MFMA4(dp, vf, dof[t]);
+                    f32x4 ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dq[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt4[r], ds[r], dq[t], 0, 0, 0);
+                }
+            }
+        }
+        stage(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float f = scale * unscale[t];
+        const float4 o = make_float4((dq[t][0] + dq2[t][0] * 0.00048828125f) * f, (dq[t][1] + dq2[t][1] * 0.00048828125f) * f,
+                                     (dq[t][2] + dq2[t][2] * 0.00048828125f) * f, (dq[t][3] + dq2[t][3] * 0.00048828125f) * f);
         *reinterpret_cast<float4*>(dQ + base + (size_t)(q0 + t * 16 + lq) * RS + 4 * g) = o;
     }
 }
@@ -251,8 +474,12 @@ static hipError_t launch_bwd(const float* q, const float* k, const float* v, con
     if (L % 128 != 0) return hipErrorInvalidValue;
     const float scale = 0.25f;  // head_dim^-1/2
     const dim3 grid((L / 128) * B * heads);
-    hipLaunchKernelGGL(k_flash_hd16_bwd_dq<2>, grid, dim3(256), 0, stream, q, k, v, o, dout, lse2, dq, delta, L, heads,
-                       B * heads, scale, lay);
+    if (attention_hd16_fp32_products())
+        hipLaunchKernelGGL(k_flash_hd16_bwd_dq<2>, grid, dim3(256), 0, stream, q, k, v, o, dout, lse2, dq, delta, L, heads,
+                           B * heads, scale, lay);
+    else
+        hipLaunchKernelGGL(k_flash_hd16_bwd_dq_h<2>, grid, dim3(256), 0, stream, q, k, v, o, dout, lse2, dq, delta, L, heads,
+                           B * heads, scale, lay);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_flash_hd16_bwd_dkv<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
