@@ -468,6 +468,274 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dK and dV with the four products on the fp16 matrix cores (the counterpart of k_flash_hd16_bwd_dq_h): the wave's keys
+// are resident as halves ([h | 2^-11 h] and [x - h | 0], K after its multiplication by hd^-1/2 log2 e), the queries
+// stream through LDS in tiles of 64, each in five forms: Q and dO rows in fp32 (fall-back), Q and G = 2^-e dO rows as
+// halves [h4 | l4] x 4 (A operands of S and dP), and Q and G as the A fragments of the two accumulating products
+// ([hi, lo][32-query half][d][g][slot], slot 4j + r <-> query 16j + 4g + r).  e is common to the 64 queries of a tile
+// (the products that accumulate dV and dK contract over queries): the staging waves exchange their maxima through LDS,
+// one more barrier per tile.  A tile's contribution is accumulated on its own and added to dK / dV times 2^e.
+//   S  = [Qh | Ql] [Kh | 2^-11 Kh]^T + [Qh | Ql] [Kl | 0]^T          dP = the same with G and V, C operand -2^-e D
+//   dV^T += Gh^T Ph + Gh^T Pl + 2^-11 Gl^T Ph                         dK^T += Qh^T dSh + Qh^T dSl + 2^-11 Ql^T dSh
+// Fall-back to the fp32 instructions of k_flash_hd16_bwd_dkv: the whole wave when one of its keys leaves the range of the
+// halves, a tile when a staged q or dO does, when the tile's dO cannot be rescaled, or when 256 max|V| + max|2^-e D| >= 2^15.
+template <int KT>
+__global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv_h(const float* __restrict__ Q, const float* __restrict__ K,
+                                                              const float* __restrict__ V, const float* __restrict__ dO,
+                                                              const float* __restrict__ LSE2, const float* __restrict__ D,
+                                                              float* __restrict__ dK, float* __restrict__ dV, int L,
+                                                              int heads, int n_bh, float scale, const QkvLayout lay) {
+    __shared__ __attribute__((aligned(16))) float Qs[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) float dOs[2][BT * BROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Qh[2][BT * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Gh[2][BT * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Qt[2][2][2][16 * 4 * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 Gt[2][2][2][16 * 4 * 8];
+    __shared__ __attribute__((aligned(16))) float NLs[2][BT];
+    __shared__ __attribute__((aligned(16))) float NDs[2][BT];
+    __shared__ float gmax_s[2][4];   // per staging wave: max |dO| of its 16 queries (before the tile is staged)
+    __shared__ float dmax_s[2][4];   // per staging wave: max |D| of its 16 queries
+    __shared__ int slow_s[2][4];     // per staging wave: a q or dO that the halves cannot hold
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bh, kblk;
+    decode_block(blockIdx.x, L / (4 * KT * 16), n_bh, bh, kblk);
+    const int k0 = kblk * (4 * KT * 16) + wave * (KT * 16);
+    const int lq = lane & 15, g = lane >> 4;
+    const int b = bh / heads, head = bh - b * heads, C = heads * 16;
+    const float scale_log2e = scale * 1.4426950408889634f;
+    const int RS = lay.rs;
+    const size_t base = (size_t)b * lay.img + (size_t)head * lay.hs;
+    const float* Qb = Q + base;
+    const float* dOb = dO + (size_t)b * L * C + head * 16;
+    const float* Lb = LSE2 + (size_t)bh * L;
+    const float* Db = D + (size_t)bh * L;
+
+    // resident operands of the wave's keys: lane (key, g) holds columns 4g .. 4g+3 of row key
+    float4 kf[KT], vf[KT];
+    f16x8 kb1[KT], kb2[KT], vb1[KT], vb2[KT];
+    f32x4 dk[KT], dv[KT];
+    bool bounded = true;
+    float vmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const size_t row = base + (size_t)(k0 + t * 16 + lq) * RS + 4 * g;
+        kf[t] = *reinterpret_cast<const float4*>(K + row);
+        kf[t].x *= scale_log2e; kf[t].y *= scale_log2e; kf[t].z *= scale_log2e; kf[t].w *= scale_log2e;
+        vf[t] = *reinterpret_cast<const float4*>(V + row);
+        dk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float kk[4] = {kf[t].x, kf[t].y, kf[t].z, kf[t].w}, vv[4] = {vf[t].x, vf[t].y, vf[t].z, vf[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 kh = (_Float16)kk[i], vh = (_Float16)vv[i];
+            kb1[t][i] = kh;
+            kb1[t][4 + i] = (_Float16)((float)kh * 0.00048828125f);
+            kb2[t][i] = (_Float16)(kk[i] - (float)kh);
+            kb2[t][4 + i] = (_Float16)0.f;
+            vb1[t][i] = vh;
+            vb1[t][4 + i] = (_Float16)((float)vh * 0.00048828125f);
+            vb2[t][i] = (_Float16)(vv[i] - (float)vh);
+            vb2[t][4 + i] = (_Float16)0.f;
+            bounded = bounded && (fabsf(kk[i]) < 32768.f) && (fabsf(vv[i]) < 32768.f);
+            vmax = fmaxf(vmax, fabsf(vv[i]));
+        }
+    }
+    vmax = wave_max(vmax);
+    const bool wave_slow = __any(!bounded) != 0;
+
+    // staging: 64 queries x 16 floats of Q and dO as rows (one float4 each per thread) and as columns (one column vd of the
+    // four queries that are neighbours in a lane's slot order); -LSE2 and -D by the first 64 threads.  The rows and the
+    // columns a wave stages belong to the same 16 queries.
+    const int srow = tid >> 2, sc4 = (tid & 3) * 4, r64 = tid & 63;
+    const int vd = lane >> 2, vg = lane & 3, vj = wave & 1, vhalf = wave >> 1;
+    const int vq = 32 * vhalf + 16 * vj + 4 * vg;
+    float4 qreg, greg, qtreg, gtreg;
+    float lreg, dreg;
+    auto load_tile = [&](int tile) {
+        qreg = *reinterpret_cast<const float4*>(Qb + (size_t)(tile * BT + srow) * RS + sc4);
+        greg = *reinterpret_cast<const float4*>(dOb + (size_t)(tile * BT + srow) * C + sc4);
+        const float* qp = Qb + (size_t)(tile * BT + vq) * RS + vd;
+        qtreg = make_float4(qp[0], qp[RS], qp[2 * RS], qp[3 * RS]);
+        const float* gp = dOb + (size_t)(tile * BT + vq) * C + vd;
+        gtreg = make_float4(gp[0], gp[C], gp[2 * C], gp[3 * C]);
+        lreg = Lb[tile * BT + r64];
+        dreg = Db[tile * BT + r64];
+    };
+    // what the staging waves tell one another before a tile is staged (read behind a barrier)
+    auto announce = [&](int buf) {
+        const float gm = wave_max(fmaxf(fmaxf(fabsf(greg.x), fabsf(greg.y)), fmaxf(fabsf(greg.z), fabsf(greg.w))));
+        if (lane == 0) gmax_s[buf][wave] = gm;
+    };
+    auto stage = [&](int buf) {
+        const float m = fmaxf(fmaxf(gmax_s[buf][0], gmax_s[buf][1]), fmaxf(gmax_s[buf][2], gmax_s[buf][3]));
+        const int ex = (int)((__float_as_uint(m) >> 23) & 0xff);
+        const bool usable = ex >= 5 && ex <= 250;
+        const float sc = usable ? __uint_as_float((unsigned)(257 - ex) << 23) : 1.0f;   // 2^-e: max |2^-e dO| in [8, 16)
+        *reinterpret_cast<float4*>(&Qs[buf][srow * BROW + sc4]) = qreg;
+        *reinterpret_cast<float4*>(&dOs[buf][srow * BROW + sc4]) = greg;
+        unsigned h[2], l[2];
+        split_scaled_pair_f16(qreg.x, qreg.y, h[0], l[0]);
+        split_scaled_pair_f16(qreg.z, qreg.w, h[1], l[1]);
+        *reinterpret_cast<u32x4*>(&Qh[buf][srow * 32 + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
+        split_scaled_pair_f16(greg.x * sc, greg.y * sc, h[0], l[0]);
+        split_scaled_pair_f16(greg.z * sc, greg.w * sc, h[1], l[1]);
+        *reinterpret_cast<u32x4*>(&Gh[buf][srow * 32 + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
+        const int at = (vd * 4 + vg) * 8 + 4 * vj;
+        split_scaled_pair_f16(qtreg.x, qtreg.y, h[0], l[0]);
+        split_scaled_pair_f16(qtreg.z, qtreg.w, h[1], l[1]);
+        *reinterpret_cast<u32x2*>(&Qt[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(&Qt[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
+        split_scaled_pair_f16(gtreg.x * sc, gtreg.y * sc, h[0], l[0]);
+        split_scaled_pair_f16(gtreg.z * sc, gtreg.w * sc, h[1], l[1]);
+        *reinterpret_cast<u32x2*>(&Gt[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(&Gt[buf][1][vhalf][at]) = u32x2{l[0], l[1]};
+        if (tid < 64) {
+            NLs[buf][r64] = -lreg;
+            NDs[buf][r64] = -dreg;
+        }
+        const float qm = fmaxf(fmaxf(fabsf(qreg.x), fabsf(qreg.y)), fmaxf(fabsf(qreg.z), fabsf(qreg.w)));
+        const bool out = !(qm < 32768.f) || !(usable || m == 0.f);
+        const int any_out = __any(out);
+        const float dm = wave_max(fabsf(dreg));   // (every wave loaded the tile's 64 values of D)
+        if (lane == 0) {
+            slow_s[buf][wave] = any_out ? 1 : 0;
+            dmax_s[buf][wave] = dm;
+        }
+    };
+    load_tile(0);
+    announce(0);
+    __syncthreads();
+    stage(0);
+    __syncthreads();
+
+    const int ntiles = L / BT;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int buf = qt & 1;
+        load_tile(min(qt + 1, ntiles - 1));
+        // the tile's scale again (as stage() formed it), and whether the halves can take it
+        const float m = fmaxf(fmaxf(gmax_s[buf][0], gmax_s[buf][1]), fmaxf(gmax_s[buf][2], gmax_s[buf][3]));
+        const int ex = (int)((__float_as_uint(m) >> 23) & 0xff);
+        const bool usable = ex >= 5 && ex <= 250;
+        const float sc = usable ? __uint_as_float((unsigned)(257 - ex) << 23) : 1.0f;
+        const float un = usable ? __uint_as_float((unsigned)(ex - 3) << 23) : 1.0f;
+        const int flagged = slow_s[buf][0] | slow_s[buf][1] | slow_s[buf][2] | slow_s[buf][3];
+        const float dm = dmax_s[buf][0] * sc;
+        const bool fast = !wave_slow && __builtin_amdgcn_readfirstlane(flagged) == 0 &&
+                          (256.f * vmax + __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dm))) < 32768.f);
+        if (fast) {
+            f32x4 dvt[KT], dvt2[KT], dkt[KT], dkt2[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                dvt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt2[t] = dvt[t]; dkt[t] = dvt[t]; dkt2[t] = dvt[t];
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 s[KT][2], dp[KT][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int jj = 2 * hf + j;
+                    const f16x8 qa = *reinterpret_cast<const f16x8*>(&Qh[buf][(jj * 16 + lq) * 32 + 8 * g]);
+                    const f16x8 ga = *reinterpret_cast<const f16x8*>(&Gh[buf][(jj * 16 + lq) * 32 + 8 * g]);
+                    const f32x4 nl = *reinterpret_cast<const f32x4*>(&NLs[buf][jj * 16 + 4 * g]);
+                    f32x4 nd = *reinterpret_cast<const f32x4*>(&NDs[buf][jj * 16 + 4 * g]);
+                    nd[0] *= sc; nd[1] *= sc; nd[2] *= sc; nd[3] *= sc;
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kb1[t], nl, 0, 0, 0);
+                        s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kb2[t], a, 0, 0, 0);
+                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vb1[t], nd, 0, 0, 0);
+                        dp[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vb2[t], c, 0, 0, 0);
+                    }
+                }
+                const f16x8 gthi = *reinterpret_cast<const f16x8*>(&Gt[buf][0][hf][(lq * 4 + g) * 8]);
+                const f16x8 gtlo = *reinterpret_cast<const f16x8*>(&Gt[buf][1][hf][(lq * 4 + g) * 8]);
+                const f16x8 qthi = *reinterpret_cast<const f16x8*>(&Qt[buf][0][hf][(lq * 4 + g) * 8]);
+                const f16x8 qtlo = *reinterpret_cast<const f16x8*>(&Qt[buf][1][hf][(lq * 4 + g) * 8]);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    u32x4 ph, pl, sh, sl;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float p[4], ds[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            p[r] = __builtin_amdgcn_exp2f(s[t][j][r]);
+                            ds[r] = p[r] * dp[t][j][r];
+                        }
+                        unsigned h0, l0, h1, l1;
+                        split_pair_f16(p[0], p[1], h0, l0);
+                        split_pair_f16(p[2], p[3], h1, l1);
+                        ph[2 * j] = h0; ph[2 * j + 1] = h1;
+                        pl[2 * j] = l0; pl[2 * j + 1] = l1;
+                        split_pair_f16(ds[0], ds[1], h0, l0);
+                        split_pair_f16(ds[2], ds[3], h1, l1);
+                        sh[2 * j] = h0; sh[2 * j + 1] = h1;
+                        sl[2 * j] = l0; sl[2 * j + 1] = l1;
+                    }
+                    const f16x8 phi = __builtin_bit_cast(f16x8, ph), plo = __builtin_bit_cast(f16x8, pl);
+                    const f16x8 dsh = __builtin_bit_cast(f16x8, sh), dsl = __builtin_bit_cast(f16x8, sl);
+                    dvt2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtlo, phi, dvt2[t], 0, 0, 0);
+                    dvt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gthi, plo, dvt[t], 0, 0, 0);
+                    dvt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gthi, phi, dvt[t], 0, 0, 0);
+                    dkt2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtlo, dsh, dkt2[t], 0, 0, 0);
+                    dkt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qthi, dsl, dkt[t], 0, 0, 0);
+                    dkt[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qthi, dsh, dkt[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dv[t][r] += (dvt[t][r] + dvt2[t][r] * 0.00048828125f) * un;
+                    dk[t][r] += (dkt[t][r] + dkt2[t][r] * 0.00048828125f) * un;
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // 16 queries at a time, fp32 instructions on the unscaled tile
+                const float4 qa = *reinterpret_cast<const float4*>(&Qs[buf][(j * 16 + lq) * BROW + 4 * g]);
+                const float4 doa = *reinterpret_cast<const float4*>(&dOs[buf][(j * 16 + lq) * BROW + 4 * g]);
+                const f32x4 nl = *reinterpret_cast<const f32x4*>(&NLs[buf][j * 16 + 4 * g]);
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(&NDs[buf][j * 16 + 4 * g]);
+                float qt4[4], dot4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qt4[r] = Qs[buf][(j * 16 + 4 * g + r) * BROW + lq];
+                    dot4[r] = dOs[buf][(j * 16 + 4 * g + r) * BROW + lq];
+                }
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    f32x4 s = nl, dp = nd;
+                    MFMA4(s, qa, kf[t]);
+                    MFMA4(dp, doa, vf[t]);
+                    f32x4 p, ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p[r] = __builtin_amdgcn_exp2f(s[r]);
+                        ds[r] = p[r] * dp[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dot4[r], p[r], dv[t], 0, 0, 0);
+                        dk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt4[r], ds[r], dk[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        announce(buf ^ 1);
+        __syncthreads();   // the maxima of the next tile are there (and every wave is done with this iteration's reads of them)
+        stage(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const size_t row = base + (size_t)(k0 + t * 16 + lq) * RS + 4 * g;
+        *reinterpret_cast<float4*>(dK + row) = make_float4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+        *reinterpret_cast<float4*>(dV + row) = make_float4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+    }
+}
+
 static hipError_t launch_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                              const float* lse2, float* dq, float* dk, float* dv, float* delta, int B, int heads, int L,
                              const QkvLayout lay, hipStream_t stream) {
@@ -482,8 +750,12 @@ static hipError_t launch_bwd(const float* q, const float* k, const float* v, con
                            B * heads, scale, lay);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flash_hd16_bwd_dkv<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
-                       B * heads, scale, lay);
+    if (attention_hd16_fp32_products())
+        hipLaunchKernelGGL(k_flash_hd16_bwd_dkv<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
+                           B * heads, scale, lay);
+    else
+        hipLaunchKernelGGL(k_flash_hd16_bwd_dkv_h<2>, grid, dim3(256), 0, stream, q, k, v, dout, lse2, delta, dk, dv, L, heads,
+                           B * heads, scale, lay);
     return hipGetLastError();
 }
 
