@@ -203,6 +203,76 @@ def test_presplit_core_reads_single_flagged_groups_from_the_fp32_operands():
         close(out[:, :, 16 * h:16 * h + 16], want[:, :, 16 * h:16 * h + 16], 1e-5, f"out, head {h}")
 
 
+BACKWARD_CASES = ["plain", "tiny_gradient", "huge_gradient", "gradient_rows_of_mixed_size", "zero_gradient_rows",
+                  "values_64_and_more", "huge_values_late", "huge_keys_late", "huge_queries", "peaked_rows", "denormal_gradient"]
+
+
+@pytest.mark.parametrize("case", BACKWARD_CASES)
+def test_core_backward_value_ranges(case):
+    """The backward kernels multiply on the fp16 matrix cores (operands split in fp16 halves, dO rescaled by a power of two
+    per 16 queries in the dQ kernel and per tile of 64 queries in the dK / dV kernel) while their operands allow it, and
+    with fp32 instructions otherwise - per wave for its own rows, per tile for the streamed ones.  Every form, and the
+    switches between them, within 1e-5 of float64 (relative to the largest entry of each gradient); and the same bits as
+    the kernels restricted to fp32 instructions wherever a case forces those anyway."""
+    B, heads, L = 2, 4, 512
+    g = torch.Generator().manual_seed(321)
+    q = torch.randn(B, heads, L, 16, generator=g)
+    k = torch.randn(B, heads, L, 16, generator=g)
+    v = torch.randn(B, heads, L, 16, generator=g)
+    dout = torch.randn(B, L, heads * 16, generator=g)
+    if case == "tiny_gradient":
+        dout *= 3e-9                         # far below the fp16 range before the rescaling
+    elif case == "huge_gradient":
+        dout *= 7e8
+    elif case == "gradient_rows_of_mixed_size":
+        dout *= torch.exp2(torch.randint(-30, 10, (B, L, 1), generator=g).float())   # every row its own magnitude
+    elif case == "zero_gradient_rows":
+        dout[:, 100:300] = 0.0               # whole tiles (and groups of 16 queries) without a gradient
+    elif case == "values_64_and_more":
+        v *= 150.0                           # 256 max|V| leaves the range a dS may take: fp32 instructions
+    elif case == "huge_values_late":
+        v[:, 1::2, 320:] *= 3e5              # the key blocks from 320 on (every second head) multiply in fp32
+    elif case == "huge_keys_late":
+        k[:, 1::2, 320:] *= 1e5
+        q[:, 1::2] *= 1e-5
+    elif case == "huge_queries":
+        q[:, ::2, 100:200] *= 2e5            # beyond the halves (the waves and tiles that hold them multiply in fp32) ...
+        k[:, ::2] *= 1e-5                    # ... with scores that stay of order one (a well-conditioned softmax)
+    elif case == "peaked_rows":
+        q *= 12.0
+    elif case == "denormal_gradient":
+        dout *= 1e-41                        # cannot be rescaled: fp32 instructions
+    want_out, want_dq, want_dk, want_dv = core_reference(q, k, v, dout)
+    out, dq, dk, dv, _ = run_core(q, k, v, dout)
+    close(out, want_out, 1e-5, "out")
+    if case == "denormal_gradient":
+        assert all(torch.isfinite(t).all() for t in (dq, dk, dv))
+        return
+    close(dq, want_dq, 1e-5, "dq")
+    close(dk, want_dk, 1e-5, "dk")
+    close(dv, want_dv, 1e-5, "dv")
+    again = run_core(q, k, v, dout)
+    for a, b2, what in zip((dq, dk, dv), again[1:4], ("dq", "dk", "dv")):
+        assert torch.equal(a, b2), f"{what}: two calls differ"
+
+
+def test_core_backward_propagates_nonfinite_gradients():
+    """An infinite or NaN entry of dO: the affected gradients are not finite, the others are untouched, nothing hangs."""
+    B, heads, L = 1, 2, 256
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, heads, L, 16, generator=g) for _ in range(3))
+    dout = torch.randn(B, L, heads * 16, generator=g)
+    clean = run_core(q, k, v, dout)
+    dout[0, 37, 3] = float("nan")            # head 0, query 37
+    _, dq, dk, dv, _ = run_core(q, k, v, dout)
+    assert not torch.isfinite(dq[0, 0, 37]).all() and not torch.isfinite(dv[0, 0]).all()
+    for got, ref in zip((dq, dk, dv), clean[1:4]):
+        assert torch.equal(got[0, 1], ref[0, 1]), "the other head changed"
+    keep = torch.ones(L, dtype=torch.bool)
+    keep[37] = False
+    assert torch.isfinite(dq[0, 0, keep]).all(), "queries other than the poisoned one lost their dq"
+
+
 def test_core_is_deterministic_and_rejects_other_shapes():
     g = torch.Generator().manual_seed(7)
     q, k, v = (torch.randn(2, 4, 256, 16, generator=g) for _ in range(3))
