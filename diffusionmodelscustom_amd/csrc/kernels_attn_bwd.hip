@@ -545,25 +545,23 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv_h(const float* __res
     const bool wave_slow = __any(!bounded) != 0;
 
     // staging: 64 queries x 16 floats of Q and dO as rows (one float4 each per thread) and as columns (one column vd of the
-    // four queries that are neighbours in a lane's slot order); -LSE2 and -D by the first 64 threads.  The rows and the
-    // columns a wave stages belong to the same 16 queries.
+    // four queries that are neighbours in a lane's slot order, read back from the fp32 rows in LDS); -LSE2 and -D by the
+    // first 64 threads.
     const int srow = tid >> 2, sc4 = (tid & 3) * 4, r64 = tid & 63;
     const int vd = lane >> 2, vg = lane & 3, vj = wave & 1, vhalf = wave >> 1;
     const int vq = 32 * vhalf + 16 * vj + 4 * vg;
-    float4 qreg, greg, qtreg, gtreg;
+    float4 qreg, greg;
     float lreg, dreg;
     auto load_tile = [&](int tile) {
         qreg = *reinterpret_cast<const float4*>(Qb + (size_t)(tile * BT + srow) * RS + sc4);
         greg = *reinterpret_cast<const float4*>(dOb + (size_t)(tile * BT + srow) * C + sc4);
-        const float* qp = Qb + (size_t)(tile * BT + vq) * RS + vd;
-        qtreg = make_float4(qp[0], qp[RS], qp[2 * RS], qp[3 * RS]);
-        const float* gp = dOb + (size_t)(tile * BT + vq) * C + vd;
-        gtreg = make_float4(gp[0], gp[C], gp[2 * C], gp[3 * C]);
         lreg = Lb[tile * BT + r64];
         dreg = Db[tile * BT + r64];
     };
     // what the staging waves tell one another before a tile is staged (read behind a barrier)
     auto announce = [&](int buf) {
+        *reinterpret_cast<float4*>(&Qs[buf][srow * BROW + sc4]) = qreg;    // (the fp32 rows: stage() reads its columns from them)
+        *reinterpret_cast<float4*>(&dOs[buf][srow * BROW + sc4]) = greg;
         const float gm = wave_max(fmaxf(fmaxf(fabsf(greg.x), fabsf(greg.y)), fmaxf(fabsf(greg.z), fabsf(greg.w))));
         if (lane == 0) gmax_s[buf][wave] = gm;
     };
@@ -572,8 +570,6 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv_h(const float* __res
         const int ex = (int)((__float_as_uint(m) >> 23) & 0xff);
         const bool usable = ex >= 5 && ex <= 250;
         const float sc = usable ? __uint_as_float((unsigned)(257 - ex) << 23) : 1.0f;   // 2^-e: max |2^-e dO| in [8, 16)
-        *reinterpret_cast<float4*>(&Qs[buf][srow * BROW + sc4]) = qreg;
-        *reinterpret_cast<float4*>(&dOs[buf][srow * BROW + sc4]) = greg;
         unsigned h[2], l[2];
         split_scaled_pair_f16(qreg.x, qreg.y, h[0], l[0]);
         split_scaled_pair_f16(qreg.z, qreg.w, h[1], l[1]);
@@ -582,6 +578,10 @@ __global__ __launch_bounds__(256) void k_flash_hd16_bwd_dkv_h(const float* __res
         split_scaled_pair_f16(greg.z * sc, greg.w * sc, h[1], l[1]);
         *reinterpret_cast<u32x4*>(&Gh[buf][srow * 32 + 2 * sc4]) = u32x4{h[0], h[1], l[0], l[1]};
         const int at = (vd * 4 + vg) * 8 + 4 * vj;
+        const float* qc = &Qs[buf][vq * BROW + vd];    // one column of four neighbouring queries, from the fp32 rows
+        const float* gc = &dOs[buf][vq * BROW + vd];
+        const float4 qtreg = make_float4(qc[0], qc[BROW], qc[2 * BROW], qc[3 * BROW]);
+        const float4 gtreg = make_float4(gc[0], gc[BROW], gc[2 * BROW], gc[3 * BROW]);
         split_scaled_pair_f16(qtreg.x, qtreg.y, h[0], l[0]);
         split_scaled_pair_f16(qtreg.z, qtreg.w, h[1], l[1]);
         *reinterpret_cast<u32x2*>(&Qt[buf][0][vhalf][at]) = u32x2{h[0], h[1]};
