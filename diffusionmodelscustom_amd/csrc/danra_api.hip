@@ -1686,11 +1686,17 @@ int danra_conv8x8s2_train_wgrad(const float* x, const float* dy, float* dw, int 
     return DANRA_OK;
 }
 
-int danra_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
+size_t danra_channel_sum_workspace(int B, int C, int HW) {
+    if (B <= 0 || C <= 0 || HW <= 0 || HW % 4) return 0;
+    const int S = channel_sum_slices(B, C, HW);
+    return S > 1 ? (size_t)S * C * sizeof(float) : 0;
+}
+
+int danra_channel_sum(const float* x, float* out, int B, int C, int HW, void* workspace, void* stream) {
     if (!x || !out) return fail(DANRA_EINVAL, "null argument");
     if (B <= 0 || C <= 0 || HW <= 0 || HW % 4 || (long long)B * C * HW >= (1LL << 31))
         return fail(DANRA_EINVAL, "B=%d C=%d HW=%d: HW must be a positive multiple of 4, fewer than 2^31 elements", B, C, HW);
-    HIP_TRY(launch_channel_sum(x, out, B, C, HW, (hipStream_t)stream));
+    HIP_TRY(launch_channel_sum(x, out, B, C, HW, static_cast<float*>(workspace), (hipStream_t)stream));
     return DANRA_OK;
 }
 

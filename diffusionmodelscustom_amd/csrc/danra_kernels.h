@@ -359,7 +359,10 @@ hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* 
                                float momentum, int relu, hipStream_t stream, const float* res = nullptr,
                                long long* batches = nullptr);
 // out[c] = sum_{b, hw} x[b][c][hw] on NCHW fp32 (HW a multiple of 4): a convolution's bias gradient; fixed summation order.
-hipError_t launch_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t stream);
+// workspace (may be null: one workgroup per channel): channel_sum_slices(B, C, HW) * C floats, large tensors are then split
+// over that many workgroups per channel and merged in order by a second kernel.
+int channel_sum_slices(int B, int C, int HW);
+hipError_t launch_channel_sum(const float* x, float* out, int B, int C, int HW, float* workspace, hipStream_t stream);
 // y is the forward's output (read only with relu, for the mask)
 hipError_t launch_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
                                const float* save_rstd, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int relu,

@@ -223,16 +223,19 @@ hipError_t launch_bn_train_fwd(const float* x, const float* gamma, const float* 
     return hipGetLastError();
 }
 
-// out[c] = sum over images and positions of x[b][c][.] (the gradient of a convolution's bias): one workgroup per channel,
-// partial sums per thread in a fixed order, then the block's tree: the same bits on every call.
+// out[c] = sum over images and positions of x[b][c][.] (the gradient of a convolution's bias).  Workgroup (c, s): channel c,
+// images s, s + S, ...; partial sums per thread in a fixed order, then the block's tree; with S > 1 the S partial sums of
+// a channel (in `part`) are added in order by k_channel_sum_merge: the same bits on every call.
 __global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW) {
     __shared__ float red[4];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int hw4 = HW / 4, per = B * hw4;
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+    const int hw4 = HW / 4;
+    const int nb = (B - s + S - 1) / S;       // images of this workgroup
+    const int per = nb * hw4;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains: the loads of four iterations in flight
     auto at = [&](int i) -> float4 {
-        const int b = i / hw4, r = i - b * hw4;
-        return *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + 4 * (size_t)r);
+        const int bi = i / hw4, r = i - bi * hw4;
+        return *reinterpret_cast<const float4*>(x + ((size_t)(s + bi * S) * C + c) * HW + 4 * (size_t)r);
     };
     int i = tid;
     for (; i + 768 < per; i += 1024) {
@@ -247,12 +250,34 @@ __global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x
         s0 += (a.x + a.y) + (a.z + a.w);
     }
     const float total = block_sum256((s0 + s1) + (s2 + s3), red);
-    if (tid == 0) out[c] = total;
+    if (tid == 0) out[(size_t)s * C + c] = total;
 }
 
-hipError_t launch_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t stream) {
+__global__ void k_channel_sum_merge(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = part[c];
+    for (int s = 1; s < S; ++s) t += part[(size_t)s * C + c];
+    out[c] = t;
+}
+
+// images per channel split over this many workgroups (1: no second kernel, no workspace)
+int channel_sum_slices(int B, int C, int HW) {
+    const long long bytes = (long long)B * HW * 4;            // per channel
+    if (bytes < (1 << 17) || C >= 256) return 1;
+    int S = 256 / C > 1 ? 512 / C : 1;                         // about 512 workgroups
+    if (S > 16) S = 16;
+    if (S > B) S = B;
+    return S < 1 ? 1 : S;
+}
+
+hipError_t launch_channel_sum(const float* x, float* out, int B, int C, int HW, float* workspace, hipStream_t stream) {
     if (B <= 0 || C <= 0 || HW <= 0 || HW % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_channel_sum, dim3(C), dim3(256), 0, stream, x, out, B, C, HW);
+    const int S = workspace ? channel_sum_slices(B, C, HW) : 1;
+    hipLaunchKernelGGL(k_channel_sum, dim3(C, S), dim3(256), 0, stream, x, S > 1 ? workspace : out, B, C, HW);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || S == 1) return e;
+    hipLaunchKernelGGL(k_channel_sum_merge, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, out, C, S);
     return hipGetLastError();
 }
 

@@ -96,7 +96,8 @@ _SIGNATURES = {
     "danra_batchnorm_train_add_relu_fwd": (ctypes.c_int, [_P] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _P, _P]),
     "danra_batchnorm_train_add_relu_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int] * 3 + [_P]),
     "danra_instancenorm_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P]),
-    "danra_channel_sum": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "danra_channel_sum_workspace": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "danra_channel_sum": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "danra_instancenorm_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "danra_linear_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "danra_linear_wgrad_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -956,9 +957,11 @@ def channel_sum(t):
             and 0 < t.numel() < (1 << 31):
         lib = load_library()
         out = torch.empty(t.shape[1], device=t.device, dtype=torch.float32)
+        B, C, HW = t.shape[0], t.shape[1], t.shape[2] * t.shape[3]
+        need = lib.danra_channel_sum_workspace(B, C, HW)
+        ws = torch.empty(need // 4, device=t.device, dtype=torch.float32) if need else None
         with torch.cuda.device(t.device):
-            _check(lib, lib.danra_channel_sum(_ptr(t), _ptr(out), t.shape[0], t.shape[1], t.shape[2] * t.shape[3], _stream()),
-                   "danra_channel_sum")
+            _check(lib, lib.danra_channel_sum(_ptr(t), _ptr(out), B, C, HW, _ptr(ws), _stream()), "danra_channel_sum")
         return out
     return t.sum((0, 2, 3))
 

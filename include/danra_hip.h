@@ -236,8 +236,10 @@ int danra_batchnorm_train_add_relu_bwd(const float* x_dev, const float* dy_dev, 
 
 /* out[c] = sum over b, h, w of x[b][c][h][w] on contiguous NCHW fp32 (HW a multiple of 4): the bias gradient of the decoder's
  * nn.Conv2d / nn.ConvTranspose2d layers (modules_DANRA_conditional.py:407-417; autograd's dy.sum((0, 2, 3))), summed in a fixed
- * order. */
-int danra_channel_sum(const float* x_dev, float* out_dev, int B, int C, int HW, void* stream);
+ * order.  workspace_dev (may be NULL): danra_channel_sum_workspace(B, C, HW) bytes; with it a large tensor is summed by several
+ * workgroups per channel and their partial sums are merged in order by a second kernel (0 bytes: not needed for the shape). */
+size_t danra_channel_sum_workspace(int B, int C, int HW);
+int danra_channel_sum(const float* x_dev, float* out_dev, int B, int C, int HW, void* workspace_dev, void* stream);
 
 /* nn.InstanceNorm2d(affine=False) as the decoder blocks use it (modules_DANRA_conditional.py:412,419) on NCHW fp32 with
  * its autograd backward, for the training step: `planes` = B*C planes of HW contiguous values each (HW a multiple of 4);
